@@ -1,0 +1,239 @@
+/*
+ * vfe.h -- C ABI of the MI355X (gfx950) visual front-end library, libvfe.so.
+ *
+ * The reference (kcenon/vi_slam) has no FFI for this path: its adapters call OpenCV
+ * in-process behind `vi_slam::ISLAMFramework::processImage(const cv::Mat&, int64_t)`
+ * (include/slam/i_slam_framework.hpp:63).  This header is the boundary a maintainer binds
+ * instead of those OpenCV calls; every entry point cites the call it replaces.
+ *
+ * Conventions
+ *  - plain C: pointers and sizes only, no C++/torch types.
+ *  - every function returns a vfe_status (0 = OK, negative = error), never throws, never
+ *    aborts; vfe_last_error() gives a thread-local message for the last failure.
+ *  - `vfe_dev_*` functions take DEVICE pointers (hipMalloc / torch.cuda memory) and a
+ *    `stream` (hipStream_t passed as void*, NULL = default stream); they only enqueue work.
+ *    They are batched: one launch processes `batch` independent frames.
+ *  - `vfe_ctx` functions take HOST pointers shaped like the fields read from a cv::Mat
+ *    (data, rows, cols, step, channels) and block until results are in the caller's
+ *    buffers.  A context is bound to one GPU and is not thread-safe (the reference
+ *    serialises calls under SLAMEngine::frameworkMutex_, src/slam/slam_engine.cpp:95).
+ *  - images are 8-bit, row-major.  Points are (x, y) float pairs.
+ *  - there is no CPU fallback: without a usable GPU every compute entry point fails with
+ *    VFE_E_NODEVICE / VFE_E_HIP.
+ */
+#ifndef VFE_H
+#define VFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFE_MAX_LEVELS 16
+
+typedef enum vfe_status {
+    VFE_OK = 0,
+    VFE_E_INVALID = -1,   /* bad argument */
+    VFE_E_HIP = -2,       /* HIP runtime error */
+    VFE_E_NOMEM = -3,     /* allocation failed / workspace too small */
+    VFE_E_CAPACITY = -4,  /* an output or internal buffer overflowed */
+    VFE_E_NODEVICE = -5   /* no usable gfx950 device */
+} vfe_status;
+
+const char* vfe_status_string(int status);
+const char* vfe_last_error(void);
+const char* vfe_version(void);
+int vfe_device_count(int* count);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched device-resident images: `batch` frames of width x height bytes; frame b starts at
+ * data + b*frame_stride, row y at + y*pitch.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vfe_dimg {
+    uint8_t* data;
+    int width, height;
+    int pitch;            /* bytes per row */
+    int batch;
+    size_t frame_stride;  /* bytes between consecutive frames */
+} vfe_dimg;
+
+/* One ORB keypoint (mirrors the fields of cv::KeyPoint that ORB fills, plus the integer
+ * position inside its pyramid level). */
+typedef struct vfe_orb_kp {
+    float x, y;      /* level-0 coordinates */
+    float size;      /* 31 * scale(level) */
+    float angle;     /* degrees, [0, 360) */
+    float response;  /* Harris response */
+    int octave;
+    int lx, ly;      /* integer coordinates in level `octave` */
+} vfe_orb_kp;
+
+/* ---- colour / intensity pre-processing ------------------------------------------------- */
+
+/* cv::cvtColor(image, gray, COLOR_BGR2GRAY) on 8-bit BGR
+ * (src/slam/adapters/openvins_adapter.cpp:72, basalt_adapter.cpp:44, orbslam3_adapter.cpp:71).
+ * bgr has 3*width bytes per row. */
+int vfe_dev_bgr2gray(const vfe_dimg* bgr, const vfe_dimg* gray, void* stream);
+
+/* ---- pyramids -------------------------------------------------------------------------- */
+
+/* cv::pyrDown: dst must be ((w+1)/2) x ((h+1)/2), same batch.  The stage the reference's
+ * configuration names as `pyramid_levels` / `num_klt_levels` (config/basalt.yaml:93,
+ * config/openvins.yaml:39). */
+int vfe_dev_pyr_down(const vfe_dimg* src, const vfe_dimg* dst, void* stream);
+
+/* cv::buildOpticalFlowPyramid: fills levels[1..nlevels-1] from levels[0]. */
+int vfe_dev_build_pyramid(const vfe_dimg* levels, int nlevels, void* stream);
+
+/* Number of the last level buildOpticalFlowPyramid(win, max_level) produces for w x h. */
+int vfe_lk_max_level(int width, int height, int win, int max_level);
+
+/* ---- Shi-Tomasi corners ---------------------------------------------------------------- */
+
+/* Bytes of device workspace vfe_dev_good_features needs. */
+size_t vfe_good_features_workspace(int width, int height, int batch, int max_corners, int seed_cap);
+
+/* cv::goodFeaturesToTrack(gray, corners, max_corners, quality, min_distance) with OpenCV's
+ * defaults (no mask, blockSize 3, Shi-Tomasi score), per frame of the batch
+ * (src/slam/adapters/openvins_adapter.cpp:79-80, src/slam/adapters/basalt_adapter.cpp:50-53).
+ *  seeds_xy [batch][seed_cap][2], n_seeds [batch] (device; NULL = none): points already being
+ *    tracked; they occupy the min-distance grid first, so new corners keep away from them
+ *    (the VINS-style "refill" the reference's max_cnt/min_dist keys imply,
+ *    config/vins_mono.yaml:92,95).  They are not returned and do not count.
+ *  corners_xy [batch][max_corners][2], scores [batch][max_corners] (may be NULL),
+ *  counts [batch]: corners found per frame, in OpenCV's order (score descending).
+ *  max_corners must be > 0. */
+int vfe_dev_good_features(const vfe_dimg* img, int max_corners, double quality, double min_distance,
+                          const float* seeds_xy, const int* n_seeds, int seed_cap,
+                          float* corners_xy, float* scores, int* counts,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* cv::cornerMinEigenVal(gray, eig, 3, 3): dense float map [batch][height][width] (debug/tests). */
+int vfe_dev_min_eigen_map(const vfe_dimg* img, float* eig, void* stream);
+
+/* ---- pyramidal Lucas-Kanade ------------------------------------------------------------ */
+
+/* cv::calcOpticalFlowPyrLK on pyramids from vfe_dev_build_pyramid -- the tracker selected by
+ * `use_klt` (config/openvins.yaml:26) / Basalt's optical flow (config/basalt.yaml:85-108);
+ * the reference names it but never calls it.
+ *  prev_levels/next_levels [nlevels]; prev_pts/next_pts [batch][pts_cap][2];
+ *  n_pts [batch] (device; NULL = pts_cap points in every frame);
+ *  status [batch][pts_cap] (1 = tracked), err [batch][pts_cap] (may be NULL).
+ *  use_initial_flow != 0: next_pts holds the initial guess (OPTFLOW_USE_INITIAL_FLOW). */
+int vfe_dev_klt_track(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                      const float* prev_pts, const int* n_pts, int pts_cap,
+                      float* next_pts, uint8_t* status, float* err,
+                      int win, int max_iter, double eps, double min_eig_thr, int use_initial_flow,
+                      void* stream);
+
+/* ---- FAST ------------------------------------------------------------------------------ */
+
+size_t vfe_fast_workspace(int width, int height, int batch);
+
+/* cv::FAST(img, kps, threshold, nonmaxSuppression=true, TYPE_9_16) per frame; keypoints as
+ * (x, y, score) int triples in raster order, kps [batch][cap][3], counts [batch]
+ * (`fast_threshold`, config/openvins.yaml:29; run on every ORB level by
+ * src/slam/adapters/orbslam3_adapter.cpp:79). */
+int vfe_dev_fast9(const vfe_dimg* img, int threshold, int* kps, int cap, int* counts,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* FAST per grid cell + best-per-cell + occupancy min distance (config/openvins.yaml:29-37:
+ * fast_threshold, grid_x, grid_y, min_px_dist, num_pts).  pts_xy [batch][cap][2],
+ * scores [batch][cap], counts [batch]; cap >= num_features + grid_x*grid_y. */
+int vfe_dev_fast_grid(const vfe_dimg* img, int threshold, int grid_x, int grid_y, int num_features,
+                      int min_px_dist, const float* seeds_xy, const int* n_seeds, int seed_cap,
+                      float* pts_xy, int* scores, int cap, int* counts,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- ORB ------------------------------------------------------------------------------- */
+
+size_t vfe_orb_workspace(int width, int height, int batch, int nfeatures, int nlevels);
+int vfe_orb_level_sizes(int width, int height, float scale_factor, int nlevels, int* wh, float* scales);
+int vfe_orb_quotas(int nfeatures, float scale_factor, int nlevels, int* quota);
+
+/* cv::ORB::create(nfeatures, scale_factor, nlevels, 31, 0, 2, HARRIS_SCORE, 31, fast_threshold)
+ *   ->detectAndCompute(gray, noArray(), keypoints, descriptors)
+ * (src/slam/adapters/orbslam3_adapter.cpp:76-79).  Keypoints of a frame come out in
+ * canonical order (octave, ly, lx); OpenCV's own order is unspecified (nth_element).
+ * kps [batch][cap], desc [batch][cap][32], counts [batch]. */
+int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float scale_factor, int nlevels,
+                        int fast_threshold, vfe_orb_kp* kps, uint8_t* desc, int cap, int* counts,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- brute-force Hamming matching -------------------------------------------------------- */
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, 2) on 256-bit descriptors (the matcher
+ * behind `knn_ratio`, docs/reference/15_openvins_smartphone_config.md:105).
+ *  out_idx/out_dist [nq][2]; train indices are reported as base_index + row, so a shard of a
+ *  larger map reports global indices; absent neighbours: idx -1, dist 0x7fffffff. */
+int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long long nt,
+                       int base_index, int* out_idx, int* out_dist, void* stream);
+
+/* Merge per-shard top-2 lists (as all-gathered from `nshards` ranks, [nshards][nq][2]) into
+ * the global top-2 by (dist, idx) -- the order a single scan over the whole map produces. */
+int vfe_dev_merge_knn2(const int* shard_idx, const int* shard_dist, int nshards, int nq,
+                       int* out_idx, int* out_dist, void* stream);
+
+/* Lowe ratio test: good[q] = 1 iff both neighbours exist and d0 < ratio * d1 (float). */
+int vfe_dev_ratio_test(const int* idx, const int* dist, int nq, float ratio, uint8_t* good, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-pointer context API (what the framework adapters call from processImage).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vfe_ctx vfe_ctx;
+
+typedef struct vfe_config {
+    int device;           /* HIP device ordinal */
+    int max_width;        /* largest frame the context will see */
+    int max_height;
+    int max_features;     /* capacity of every point list */
+    int pyramid_levels;   /* LK pyramid levels including level 0 (maxLevel + 1) */
+    int win_size;         /* LK window (21) */
+    int orb_levels;       /* 0 = ORB not used */
+} vfe_config;
+
+typedef struct vfe_frame_stats {
+    int n_tracked;        /* points carried over from the previous frame by KLT */
+    int n_detected;       /* new corners added this frame */
+    int n_total;          /* points alive after this frame */
+} vfe_frame_stats;
+
+int vfe_create(const vfe_config* cfg, vfe_ctx** out);
+void vfe_destroy(vfe_ctx* ctx);
+/* forget the previous frame and all tracks (ISLAMFramework::reset, i_slam_framework.hpp:103) */
+int vfe_reset(vfe_ctx* ctx);
+
+/* goodFeaturesToTrack on a host image (channels 1 or 3; 3 = BGR, converted on the GPU). */
+int vfe_detect_shi_tomasi(vfe_ctx* ctx, const uint8_t* data, int rows, int cols, size_t step, int channels,
+                          int max_corners, double quality, double min_distance,
+                          float* corners_xy, int* n_out);
+
+/* calcOpticalFlowPyrLK between two host images. */
+int vfe_klt_track(vfe_ctx* ctx, const uint8_t* prev, const uint8_t* next, int rows, int cols, size_t step,
+                  const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err,
+                  int max_level, int max_iter, double eps, double min_eig_thr);
+
+/* ORB::detectAndCompute on a host image. */
+int vfe_orb_extract(vfe_ctx* ctx, const uint8_t* data, int rows, int cols, size_t step, int channels,
+                    int nfeatures, float scale_factor, int nlevels, int fast_threshold,
+                    vfe_orb_kp* kps, uint8_t* desc, int cap, int* n_out);
+
+/* knnMatch(k=2) + ratio test on host descriptors. */
+int vfe_match_knn2(vfe_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                   float ratio, int* idx, int* dist, uint8_t* good);
+
+/* One front-end step of a live stream: pyramid of the new frame, KLT from the previous
+ * frame's points, refill with Shi-Tomasi corners up to max_corners.  The first frame after
+ * create/reset only detects. */
+int vfe_process_frame(vfe_ctx* ctx, const uint8_t* data, int rows, int cols, size_t step, int channels,
+                      int64_t timestamp_ns, int max_corners, double quality, double min_distance,
+                      vfe_frame_stats* stats);
+/* current points of the stream (after vfe_process_frame) */
+int vfe_get_points(vfe_ctx* ctx, float* pts_xy, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFE_H */

@@ -1,0 +1,134 @@
+"""GPU parity: HIP kernels (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bar: bit-exact for pyramids, eigenvalue maps, corner lists; KLT positions are compared
+bit-exactly as well (the tolerance the front-end is held to is 1e-3 px).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+from vi_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def to_dev(imgs, cuda, align=256):
+    import torch
+    imgs = np.stack(imgs)
+    b, h, w = imgs.shape
+    t = capi.alloc_image(b, h, w, cuda, align)
+    t.copy_(torch.from_numpy(imgs).to(cuda))
+    return t
+
+
+@pytest.mark.parametrize("w,h", [(752, 480), (640, 480), (333, 217), (64, 40), (1920, 1080)])
+def test_pyr_down_bit_exact(cuda, w, h):
+    imgs = [synth.noise(7 + i, w, h) for i in range(2)] + [synth.scene(synth.BASE_SEED, w, h, 0)]
+    d = capi.pyr_down(to_dev(imgs, cuda)).cpu().numpy()
+    for i, im in enumerate(imgs):
+        assert np.array_equal(d[i], ora.pyr_down(im)), f"frame {i}"
+
+
+def test_pyr_down_unaligned_pitch(cuda):
+    import torch
+    w, h = 301, 203
+    im = synth.noise(3, w, h)
+    src = torch.empty((1, h, w + 3), dtype=torch.uint8, device=cuda)[:, :, :w]  # pitch 304-? not a multiple of 4
+    src = torch.empty((1, h, w), dtype=torch.uint8, device=cuda)                 # pitch 301
+    src.copy_(torch.from_numpy(im)[None].to(cuda))
+    dst = torch.empty((1, (h + 1) // 2, (w + 1) // 2), dtype=torch.uint8, device=cuda)
+    capi.pyr_down(src, dst)
+    assert np.array_equal(dst[0].cpu().numpy(), ora.pyr_down(im))
+
+
+def test_build_pyramid_4_levels(cuda):
+    w, h = 752, 480
+    im = synth.scene(synth.BASE_SEED + 1, w, h, 3)
+    lv = capi.build_pyramid(capi.alloc_pyramid(to_dev([im], cuda), 4))
+    ref = ora.build_pyramid(im, 21, 3)
+    assert len(ref) == 4
+    for a, r in zip(lv, ref):
+        assert np.array_equal(a[0].cpu().numpy(), r)
+
+
+@pytest.mark.parametrize("w,h", [(752, 480), (130, 70), (64, 16), (65, 33)])
+def test_min_eigen_map_bit_exact(cuda, w, h):
+    imgs = [synth.scene(synth.BASE_SEED, w, h, 0), synth.noise(11, w, h)]
+    e = capi.min_eigen_map(to_dev(imgs, cuda)).cpu().numpy()
+    for i, im in enumerate(imgs):
+        r = ora.min_eigen_map(im)
+        assert np.array_equal(e[i].view(np.uint32), r.view(np.uint32)), f"frame {i}: max abs diff {np.abs(e[i]-r).max()}"
+
+
+@pytest.mark.parametrize("w,h,n,q,d", [(752, 480, 150, 0.01, 30), (752, 480, 200, 0.01, 10), (640, 480, 200, 0.007, 10),
+                                       (320, 240, 500, 0.01, 1), (320, 240, 300, 0.05, 0), (1920, 1080, 1000, 0.01, 20),
+                                       (200, 100, 50, 0.01, 7.5)])
+def test_good_features_bit_exact(cuda, w, h, n, q, d):
+    imgs = [synth.scene(synth.BASE_SEED + 2, w, h, 0), synth.noise(5, w, h), np.full((h, w), 128, np.uint8)]
+    gf = capi.GoodFeatures(len(imgs), h, w, n, device=cuda)
+    c, s, cnt = gf(to_dev(imgs, cuda), q, d)
+    c, s, cnt = c.cpu().numpy(), s.cpu().numpy(), cnt.cpu().numpy()
+    for i, im in enumerate(imgs):
+        rxy, rsc = ora.good_features(im, n, q, d)
+        assert cnt[i] == len(rxy), f"frame {i}: {cnt[i]} vs {len(rxy)}"
+        assert np.array_equal(c[i, :cnt[i]], rxy), f"frame {i}"
+        assert np.array_equal(s[i, :cnt[i]].view(np.uint32), rsc.view(np.uint32))
+    assert cnt[2] == 0  # constant image: no corners (reference fixture tests/test_slam_engine.cpp:94)
+
+
+def test_good_features_with_seeds(cuda):
+    import torch
+    w, h, n, d = 752, 480, 150, 30
+    im0 = synth.scene(synth.BASE_SEED, w, h, 0)
+    im1 = synth.scene(synth.BASE_SEED, w, h, 1)
+    seeds, _ = ora.good_features(im0, 100, 0.01, d)
+    rxy, _ = ora.good_features(im1, n - len(seeds), 0.01, d, seeds=seeds)
+    gf = capi.GoodFeatures(1, h, w, n - len(seeds), seed_cap=128, device=cuda)
+    sd = torch.zeros((1, 128, 2), dtype=torch.float32, device=cuda)
+    sd[0, :len(seeds)] = torch.from_numpy(seeds).to(cuda)
+    ns = torch.tensor([len(seeds)], dtype=torch.int32, device=cuda)
+    c, _, cnt = gf(to_dev([im1], cuda), 0.01, d, sd, ns)
+    k = int(cnt[0])
+    assert k == len(rxy)
+    assert np.array_equal(c[0, :k].cpu().numpy(), rxy)
+    # every new corner keeps the minimum distance from every seed
+    dd = np.linalg.norm(rxy[:, None, :] - np.round(seeds)[None], axis=2)
+    assert dd.min() >= d
+
+
+@pytest.mark.parametrize("w,h,levels,npts", [(752, 480, 3, 150), (320, 240, 4, 80), (1920, 1080, 4, 300)])
+def test_klt_parity(cuda, w, h, levels, npts):
+    import torch
+    seqs = [(synth.BASE_SEED + s) for s in range(2)]
+    prev = [synth.scene(s, w, h, 0) for s in seqs]
+    nxt = [synth.scene(s, w, h, 1) for s in seqs]
+    pts = []
+    for im in prev:
+        xy, _ = ora.good_features(im, npts, 0.01, 10)
+        # add sub-pixel offsets and a few points near / outside the border
+        xy = xy + np.float32(0.25) * (np.arange(len(xy))[:, None] % 4).astype(np.float32)
+        xy[:3] = [[1.5, 2.25], [w - 2.0, h - 1.5], [-5.0, 10.0]]
+        pts.append(xy)
+    cap = max(len(p) for p in pts)
+    P = np.zeros((2, cap, 2), np.float32)
+    n = np.array([len(p) for p in pts], np.int32)
+    for i, p in enumerate(pts):
+        P[i, :len(p)] = p
+    pl = capi.build_pyramid(capi.alloc_pyramid(to_dev(prev, cuda), levels))
+    nl = capi.build_pyramid(capi.alloc_pyramid(to_dev(nxt, cuda), levels))
+    out, st, err = capi.klt_track(pl, nl, torch.from_numpy(P).to(cuda), torch.from_numpy(n).to(cuda))
+    out, st, err = out.cpu().numpy(), st.cpu().numpy(), err.cpu().numpy()
+    for i in range(2):
+        ro, rs, re = ora.klt_track(prev[i], nxt[i], pts[i], 21, levels - 1)
+        k = n[i]
+        assert np.array_equal(st[i, :k], rs), f"status differs at {np.nonzero(st[i,:k]!=rs)[0][:10]}"
+        good = rs.astype(bool)
+        assert good.sum() > k // 2
+        dmax = np.abs(out[i, :k] - ro).max()
+        assert dmax <= 1e-3, f"max position difference {dmax} px (tolerance 1e-3)"
+        assert np.array_equal(out[i, :k].view(np.uint32), ro.view(np.uint32)), f"not bit-exact, max diff {dmax}"
+        assert np.array_equal(err[i, :k].view(np.uint32), re.view(np.uint32))
+        assert not st[i, k:].any()
+        # the scene moves by (-1.5, -0.75) px/frame plus a small rotation: flow must be close to that
+        flow = (ro - pts[i])[good]
+        assert np.abs(np.median(flow, axis=0) - [-1.5, -0.75]).max() < 0.5

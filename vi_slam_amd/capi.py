@@ -1,0 +1,220 @@
+"""ctypes binding of the C ABI in include/vfe.h (vi_slam_amd/lib/libvfe.so).
+
+PyTorch is only plumbing here: it owns device memory and streams; every computation goes
+through the C entry points.  There is no CPU fallback -- a missing library or GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvfe.so")
+_LIB = None
+
+VFE_MAX_LEVELS = 16
+
+
+class VfeError(RuntimeError):
+    pass
+
+
+class DImg(C.Structure):
+    """struct vfe_dimg"""
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("pitch", C.c_int),
+                ("batch", C.c_int), ("frame_stride", C.c_size_t)]
+
+
+class OrbKp(C.Structure):
+    """struct vfe_orb_kp"""
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int), ("lx", C.c_int), ("ly", C.c_int)]
+
+
+ORB_KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                         ("response", "<f4"), ("octave", "<i4"), ("lx", "<i4"), ("ly", "<i4")])
+
+
+class Config(C.Structure):
+    """struct vfe_config"""
+    _fields_ = [("device", C.c_int), ("max_width", C.c_int), ("max_height", C.c_int), ("max_features", C.c_int),
+                ("pyramid_levels", C.c_int), ("win_size", C.c_int), ("orb_levels", C.c_int)]
+
+
+class FrameStats(C.Structure):
+    """struct vfe_frame_stats"""
+    _fields_ = [("n_tracked", C.c_int), ("n_detected", C.c_int), ("n_total", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/vfe.h declares
+_P = C.c_void_p
+_DI = C.POINTER(DImg)
+SIGNATURES = {
+    "vfe_status_string": (C.c_char_p, [C.c_int]),
+    "vfe_last_error": (C.c_char_p, []),
+    "vfe_version": (C.c_char_p, []),
+    "vfe_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "vfe_dev_bgr2gray": (C.c_int, [_DI, _DI, _P]),
+    "vfe_dev_pyr_down": (C.c_int, [_DI, _DI, _P]),
+    "vfe_dev_build_pyramid": (C.c_int, [_DI, C.c_int, _P]),
+    "vfe_lk_max_level": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfe_good_features_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfe_dev_good_features": (C.c_int, [_DI, C.c_int, C.c_double, C.c_double, _P, _P, C.c_int, _P, _P, _P, _P,
+                                        C.c_size_t, _P]),
+    "vfe_dev_min_eigen_map": (C.c_int, [_DI, _P, _P]),
+    "vfe_dev_klt_track": (C.c_int, [_DI, _DI, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_double,
+                                    C.c_double, C.c_int, _P]),
+    "vfe_fast_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "vfe_dev_fast9": (C.c_int, [_DI, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, _P]),
+    "vfe_dev_fast_grid": (C.c_int, [_DI, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P,
+                                    C.c_int, _P, _P, C.c_size_t, _P]),
+    "vfe_orb_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfe_orb_level_sizes": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, _P, _P]),
+    "vfe_orb_quotas": (C.c_int, [C.c_int, C.c_float, C.c_int, _P]),
+    "vfe_dev_orb_extract": (C.c_int, [_DI, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P,
+                                      C.c_size_t, _P]),
+    "vfe_dev_match_knn2": (C.c_int, [_P, C.c_int, _P, C.c_longlong, C.c_int, _P, _P, _P]),
+    "vfe_dev_merge_knn2": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "vfe_dev_ratio_test": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P]),
+    "vfe_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "vfe_destroy": (None, [_P]),
+    "vfe_reset": (C.c_int, [_P]),
+    "vfe_detect_shi_tomasi": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, _P, C.POINTER(C.c_int)]),
+    "vfe_klt_track": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int,
+                                C.c_double, C.c_double]),
+    "vfe_orb_extract": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int,
+                                  C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "vfe_match_knn2": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_float, _P, _P, _P]),
+    "vfe_process_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int64, C.c_int, C.c_double,
+                                    C.c_double, C.POINTER(FrameStats)]),
+    "vfe_get_points": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+}
+
+
+def lib():
+    """Load libvfe.so (built in-tree by `make`).  Raises if it is missing: there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise VfeError(f"{LIB_PATH} not found: build it with `make` (hipcc --offload-arch=gfx950)")
+        L = C.CDLL(LIB_PATH)
+        missing = [name for name in SIGNATURES if not hasattr(L, name)]
+        if missing:
+            raise VfeError(f"{LIB_PATH} does not export {missing}: stale build, run `make`")
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        L = lib()
+        raise VfeError(f"{L.vfe_status_string(rc).decode()}: {L.vfe_last_error().decode()}")
+
+
+def dimg(t):
+    """vfe_dimg view of a torch uint8 CUDA tensor [B, H, W] (row stride may exceed W)."""
+    assert t.is_cuda and t.dim() == 3 and t.element_size() == 1 and t.stride(2) == 1
+    b, h, w = t.shape
+    return DImg(t.data_ptr(), w, h, t.stride(1), b, max(t.stride(0), t.stride(1) * h))
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ---- thin helpers over the device entry points (torch tensors in, torch tensors out) ----------
+
+def alloc_image(batch, h, w, device="cuda", align=256):
+    """uint8 [B, H, W] view whose rows and frames start on `align`-byte boundaries."""
+    import torch
+    pitch = (w + align - 1) // align * align
+    buf = torch.empty((batch, h, pitch), dtype=torch.uint8, device=device)
+    return buf[:, :, :w]
+
+
+def pyr_down(src, dst=None):
+    b, h, w = src.shape
+    if dst is None:
+        dst = alloc_image(b, (h + 1) // 2, (w + 1) // 2, src.device)
+    check(lib().vfe_dev_pyr_down(C.byref(dimg(src)), C.byref(dimg(dst)), _stream()))
+    return dst
+
+
+def lk_max_level(w, h, win, max_level):
+    return lib().vfe_lk_max_level(w, h, win, max_level)
+
+
+def alloc_pyramid(img, nlevels):
+    lv = [img]
+    for _ in range(1, nlevels):
+        b, h, w = lv[-1].shape
+        lv.append(alloc_image(b, (h + 1) // 2, (w + 1) // 2, img.device))
+    return lv
+
+
+def build_pyramid(levels):
+    """Fill levels[1:] from levels[0] (tensors from alloc_pyramid)."""
+    arr = (DImg * len(levels))(*[dimg(t) for t in levels])
+    check(lib().vfe_dev_build_pyramid(arr, len(levels), _stream()))
+    return levels
+
+
+class GoodFeatures:
+    """Reusable buffers for vfe_dev_good_features on [B, H, W] batches."""
+
+    def __init__(self, batch, h, w, max_corners, seed_cap=0, device="cuda"):
+        import torch
+        self.batch, self.h, self.w, self.max_corners, self.seed_cap = batch, h, w, max_corners, seed_cap
+        nbytes = lib().vfe_good_features_workspace(w, h, batch, max_corners, seed_cap)
+        if nbytes == 0:
+            raise VfeError("vfe_good_features_workspace: invalid shape")
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.ws_bytes = nbytes
+        self.corners = torch.zeros((batch, max_corners, 2), dtype=torch.float32, device=device)
+        self.scores = torch.zeros((batch, max_corners), dtype=torch.float32, device=device)
+        self.counts = torch.zeros(batch, dtype=torch.int32, device=device)
+
+    def __call__(self, img, quality, min_distance, seeds=None, n_seeds=None):
+        assert tuple(img.shape) == (self.batch, self.h, self.w)
+        check(lib().vfe_dev_good_features(C.byref(dimg(img)), self.max_corners, quality, min_distance,
+                                          _ptr(seeds), _ptr(n_seeds), self.seed_cap if seeds is not None else 0,
+                                          _ptr(self.corners), _ptr(self.scores), _ptr(self.counts),
+                                          _ptr(self.ws), self.ws_bytes, _stream()))
+        return self.corners, self.scores, self.counts
+
+
+def min_eigen_map(img):
+    import torch
+    b, h, w = img.shape
+    out = torch.empty((b, h, w), dtype=torch.float32, device=img.device)
+    check(lib().vfe_dev_min_eigen_map(C.byref(dimg(img)), _ptr(out), _stream()))
+    return out
+
+
+def klt_track(prev_levels, next_levels, prev_pts, n_pts=None, next_pts=None, status=None, err=None,
+              win=21, max_iter=30, eps=0.01, min_eig_thr=1e-4, use_initial_flow=False):
+    """prev_pts [B, cap, 2] float32 cuda; returns (next_pts, status, err)."""
+    import torch
+    b, cap, _ = prev_pts.shape
+    if next_pts is None:
+        next_pts = torch.zeros_like(prev_pts)
+    if status is None:
+        status = torch.zeros((b, cap), dtype=torch.uint8, device=prev_pts.device)
+    if err is None:
+        err = torch.zeros((b, cap), dtype=torch.float32, device=prev_pts.device)
+    n = len(prev_levels)
+    pa = (DImg * n)(*[dimg(t) for t in prev_levels])
+    na = (DImg * n)(*[dimg(t) for t in next_levels])
+    check(lib().vfe_dev_klt_track(pa, na, n, _ptr(prev_pts), _ptr(n_pts), cap, _ptr(next_pts), _ptr(status),
+                                  _ptr(err), win, max_iter, eps, min_eig_thr, 1 if use_initial_flow else 0, _stream()))
+    return next_pts, status, err

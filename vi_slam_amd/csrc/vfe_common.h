@@ -1,0 +1,75 @@
+/* Shared host/device helpers of libvfe (gfx950 only). */
+#ifndef VFE_COMMON_H
+#define VFE_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "vfe.h"
+
+void vfe_set_error(const char* fmt, ...);
+
+#define VFE_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            vfe_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? VFE_E_NOMEM                                   \
+                   : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? VFE_E_NODEVICE : VFE_E_HIP; \
+        }                                                                                      \
+    } while (0)
+
+#define VFE_REQUIRE(cond, msg)                               \
+    do {                                                     \
+        if (!(cond)) {                                       \
+            vfe_set_error("invalid argument: %s", msg);      \
+            return VFE_E_INVALID;                            \
+        }                                                    \
+    } while (0)
+
+#define VFE_LAUNCH_CHECK()                                                                 \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) {                                                            \
+            vfe_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return VFE_E_HIP;                                                              \
+        }                                                                                  \
+    } while (0)
+
+/* plain-data view of one batched image, passed to kernels by value */
+struct DImg {
+    uint8_t* data;
+    int w, h, pitch, batch;
+    size_t fstride;
+    __host__ __device__ const uint8_t* frame(int b) const { return data + (size_t)b * fstride; }
+    __host__ __device__ uint8_t* frame(int b) { return data + (size_t)b * fstride; }
+};
+
+static inline DImg to_dimg(const vfe_dimg* v) {
+    DImg d; d.data = v->data; d.w = v->width; d.h = v->height; d.pitch = v->pitch; d.batch = v->batch;
+    d.fstride = v->frame_stride; return d;
+}
+
+static inline int vfe_check_dimg(const vfe_dimg* v, const char* name) {
+    if (!v || !v->data || v->width <= 0 || v->height <= 0 || v->batch <= 0 || v->pitch < v->width ||
+        v->frame_stride < (size_t)v->pitch * (size_t)(v->height - 1) + (size_t)v->width) {
+        vfe_set_error("invalid argument: bad image descriptor %s", name);
+        return VFE_E_INVALID;
+    }
+    return VFE_OK;
+}
+
+/* BORDER_REFLECT_101 */
+__host__ __device__ static inline int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p;
+        else p = 2 * n - 2 - p;
+    }
+    return p;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+#endif

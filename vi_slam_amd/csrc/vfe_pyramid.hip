@@ -1,0 +1,129 @@
+/* pyrDown / LK pyramid construction for gfx950.
+ *
+ * HBM-bound stencil: each 256-thread workgroup produces a 128x16 tile of the half-resolution
+ * level.  The 35 x 264-byte source tile is read once from HBM with coalesced dword loads
+ * (reflect-101 resolved per byte only on the image rim), staged in LDS, filtered
+ * horizontally into 16-bit row sums in LDS and then vertically; both passes use the
+ * [1 4 6 4 1] taps in integers with a single rounding, (sum + 128) >> 8, exactly like
+ * cv::pyrDown.  Algorithmic traffic per output pixel: 4 source bytes + 1 written byte.
+ */
+#include "vfe_common.h"
+
+#define PD_TW 128
+#define PD_TH 16
+#define PD_IN_ROWS (2 * PD_TH + 3)
+#define PD_IN_DW (2 * PD_TW / 4 + 2)
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_pyr_down(DImg src, DImg dst) {
+    __shared__ __align__(16) uint32_t s_in[PD_IN_ROWS][PD_IN_DW];
+    __shared__ __align__(16) uint16_t s_h[PD_IN_ROWS][PD_TW];
+    const int b = blockIdx.z;
+    const uint8_t* sp = src.frame(b);
+    uint8_t* dp = dst.frame(b);
+    const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
+    const int gx0 = 2 * ox - 4, gy0 = 2 * oy - 2;
+
+    for (int i = threadIdx.x; i < PD_IN_ROWS * PD_IN_DW; i += 256) {
+        const int r = i / PD_IN_DW, k = i - r * PD_IN_DW;
+        const int sy = reflect101(gy0 + r, src.h);
+        const int c = gx0 + 4 * k;
+        const uint8_t* row = sp + (size_t)sy * src.pitch;
+        uint32_t v;
+        if (ALIGNED && c >= 0 && c + 3 < src.w) {
+            v = *reinterpret_cast<const uint32_t*>(row + c);
+        } else if (c - 4 >= 2 * src.w) {
+            v = 0; /* columns no output of this tile can reach */
+        } else {
+            v = (uint32_t)row[reflect101(c, src.w)] | ((uint32_t)row[reflect101(c + 1, src.w)] << 8) |
+                ((uint32_t)row[reflect101(c + 2, src.w)] << 16) | ((uint32_t)row[reflect101(c + 3, src.w)] << 24);
+        }
+        s_in[r][k] = v;
+    }
+    __syncthreads();
+
+    /* horizontal pass: 4 outputs per item from 16 staged bytes; tile byte index of output x,
+     * tap k is 2x + 2 + k */
+    for (int i = threadIdx.x; i < PD_IN_ROWS * (PD_TW / 4); i += 256) {
+        const int r = i / (PD_TW / 4), j = i % (PD_TW / 4);
+        const uint2 lo = *reinterpret_cast<const uint2*>(&s_in[r][2 * j]);
+        const uint2 hi = *reinterpret_cast<const uint2*>(&s_in[r][2 * j + 2]);
+        const uint32_t b2 = (lo.x >> 16) & 255, b3 = lo.x >> 24;
+        const uint32_t b4 = lo.y & 255, b5 = (lo.y >> 8) & 255, b6 = (lo.y >> 16) & 255, b7 = lo.y >> 24;
+        const uint32_t b8 = hi.x & 255, b9 = (hi.x >> 8) & 255, b10 = (hi.x >> 16) & 255, b11 = hi.x >> 24;
+        const uint32_t b12 = hi.y & 255;
+        const uint32_t o0 = b2 + 4 * b3 + 6 * b4 + 4 * b5 + b6;
+        const uint32_t o1 = b4 + 4 * b5 + 6 * b6 + 4 * b7 + b8;
+        const uint32_t o2 = b6 + 4 * b7 + 6 * b8 + 4 * b9 + b10;
+        const uint32_t o3 = b8 + 4 * b9 + 6 * b10 + 4 * b11 + b12;
+        *reinterpret_cast<uint2*>(&s_h[r][4 * j]) = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));
+    }
+    __syncthreads();
+
+    /* vertical pass on packed pairs of 16-bit sums: 16*4080 + 128 < 65536, so the two halves
+     * of a dword never carry into each other */
+    for (int i = threadIdx.x; i < PD_TH * (PD_TW / 4); i += 256) {
+        const int y = i / (PD_TW / 4), j = i % (PD_TW / 4);
+        const int dy = oy + y, dx = ox + 4 * j;
+        if (dy >= dst.h || dx >= dst.w) continue;
+        const uint2 r0 = *reinterpret_cast<const uint2*>(&s_h[2 * y][4 * j]);
+        const uint2 r1 = *reinterpret_cast<const uint2*>(&s_h[2 * y + 1][4 * j]);
+        const uint2 r2 = *reinterpret_cast<const uint2*>(&s_h[2 * y + 2][4 * j]);
+        const uint2 r3 = *reinterpret_cast<const uint2*>(&s_h[2 * y + 3][4 * j]);
+        const uint2 r4 = *reinterpret_cast<const uint2*>(&s_h[2 * y + 4][4 * j]);
+        const uint32_t t0 = r0.x + 4 * r1.x + 6 * r2.x + 4 * r3.x + r4.x + 0x00800080u;
+        const uint32_t t1 = r0.y + 4 * r1.y + 6 * r2.y + 4 * r3.y + r4.y + 0x00800080u;
+        const uint32_t p0 = (t0 >> 8) & 255, p1 = t0 >> 24, p2 = (t1 >> 8) & 255, p3 = t1 >> 24;
+        uint8_t* drow = dp + (size_t)dy * dst.pitch + dx;
+        if (ALIGNED && dx + 3 < dst.w) {
+            *reinterpret_cast<uint32_t*>(drow) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+        } else {
+            drow[0] = (uint8_t)p0;
+            if (dx + 1 < dst.w) drow[1] = (uint8_t)p1;
+            if (dx + 2 < dst.w) drow[2] = (uint8_t)p2;
+            if (dx + 3 < dst.w) drow[3] = (uint8_t)p3;
+        }
+    }
+}
+
+static bool dword_ok(const DImg& d) {
+    return ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
+}
+
+static int launch_pyr_down(const DImg& s, const DImg& d, hipStream_t st) {
+    dim3 grid(div_up(d.w, PD_TW), div_up(d.h, PD_TH), d.batch);
+    if (dword_ok(s) && dword_ok(d))
+        hipLaunchKernelGGL(k_pyr_down<true>, grid, dim3(256), 0, st, s, d);
+    else
+        hipLaunchKernelGGL(k_pyr_down<false>, grid, dim3(256), 0, st, s, d);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
+extern "C" int vfe_dev_pyr_down(const vfe_dimg* src, const vfe_dimg* dst, void* stream) {
+    int rc;
+    if ((rc = vfe_check_dimg(src, "src")) || (rc = vfe_check_dimg(dst, "dst"))) return rc;
+    VFE_REQUIRE(dst->width == (src->width + 1) / 2 && dst->height == (src->height + 1) / 2, "dst must be ((w+1)/2, (h+1)/2)");
+    VFE_REQUIRE(dst->batch == src->batch, "batch mismatch");
+    VFE_REQUIRE(src->batch <= 65535, "batch too large");
+    return launch_pyr_down(to_dimg(src), to_dimg(dst), (hipStream_t)stream);
+}
+
+extern "C" int vfe_dev_build_pyramid(const vfe_dimg* levels, int nlevels, void* stream) {
+    VFE_REQUIRE(levels && nlevels >= 1 && nlevels <= VFE_MAX_LEVELS, "nlevels out of range");
+    for (int l = 1; l < nlevels; l++) {
+        int rc = vfe_dev_pyr_down(&levels[l - 1], &levels[l], stream);
+        if (rc) return rc;
+    }
+    return VFE_OK;
+}
+
+extern "C" int vfe_lk_max_level(int w, int h, int win, int max_level) {
+    int level = 0;
+    for (; level < max_level; level++) {
+        int nw = (w + 1) / 2, nh = (h + 1) / 2;
+        if (nw <= win || nh <= win) break;
+        w = nw; h = nh;
+    }
+    return level;
+}
