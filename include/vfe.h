@@ -99,9 +99,10 @@ size_t vfe_good_features_workspace(int width, int height, int batch, int max_cor
  * defaults (no mask, blockSize 3, Shi-Tomasi score), per frame of the batch
  * (src/slam/adapters/openvins_adapter.cpp:79-80, src/slam/adapters/basalt_adapter.cpp:50-53).
  *  seeds_xy [batch][seed_cap][2], n_seeds [batch] (device; NULL = none): points already being
- *    tracked; they occupy the min-distance grid first, so new corners keep away from them
- *    (the VINS-style "refill" the reference's max_cnt/min_dist keys imply,
- *    config/vins_mono.yaml:92,95).  They are not returned and do not count.
+ *    tracked; they occupy the min-distance grid first, so new corners keep away from them,
+ *    and frame b returns at most max_corners - n_seeds[b] new corners (the VINS-style
+ *    "refill" the reference's max_cnt/min_dist keys imply, config/vins_mono.yaml:92,95).
+ *    Seeds themselves are not returned.
  *  corners_xy [batch][max_corners][2], scores [batch][max_corners] (may be NULL),
  *  counts [batch]: corners found per frame, in OpenCV's order (score descending).
  *  max_corners must be > 0. */
@@ -127,6 +128,48 @@ int vfe_dev_klt_track(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, 
                       float* next_pts, uint8_t* status, float* err,
                       int win, int max_iter, double eps, double min_eig_thr, int use_initial_flow,
                       void* stream);
+
+/* ---- batched front-end step ------------------------------------------------------------- */
+
+/* After tracking: keep the points with status != 0 whose rounded position lies inside
+ * [border, width-border) x [border, height-border), preserving order.
+ * pts/status [batch][cap], n_pts [batch] (NULL = cap); out_pts [batch][cap][2], out_n [batch]. */
+int vfe_dev_compact_tracks(const float* pts, const uint8_t* status, const int* n_pts, int cap, int batch,
+                           int width, int height, int border, float* out_pts, int* out_n, void* stream);
+
+/* pts[b][n_pts[b] + i] = extra[b][i] for i < n_extra[b]; n_pts[b] += n_extra[b] (clamped to cap). */
+int vfe_dev_append_points(float* pts, int* n_pts, int cap, int batch,
+                          const float* extra, const int* n_extra, int extra_cap, void* stream);
+
+size_t vfe_frontend_workspace(int width, int height, int batch, int max_corners);
+
+/* One steady-state front-end step for `batch` independent streams, everything on the GPU:
+ *   1. pyramid of the new frame (next_levels[1..] from next_levels[0]),
+ *   2. KLT from prev_levels to next_levels for the pts/n_pts of each stream,
+ *   3. drop lost / out-of-border tracks,
+ *   4. refill with Shi-Tomasi corners of the new frame up to max_corners, min_distance away
+ *      from surviving tracks.
+ * pts [batch][max_corners][2] and n_pts [batch] are updated in place to the new point set
+ * (tracked points first, in order, then new corners by descending score).
+ * n_tracked [batch] (may be NULL) receives the number of surviving tracks.
+ * This is the batched form of what the adapters do per processImage call. */
+int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                          float* pts, int* n_pts, int* n_tracked, int max_corners,
+                          double quality, double min_distance,
+                          int win, int max_iter, double eps, double min_eig_thr,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- kernel timing (HIP events recorded around every kernel the library launches) ------- */
+enum { VFE_K_PYR_DOWN = 0, VFE_K_GFTT_EIG, VFE_K_GFTT_SELECT, VFE_K_KLT, VFE_K_COMPACT, VFE_K_APPEND,
+       VFE_K_FAST, VFE_K_ORB_RESIZE, VFE_K_ORB_BLUR, VFE_K_ORB_SELECT, VFE_K_ORB_DESC, VFE_K_MATCH,
+       VFE_K_MISC, VFE_K_COUNT };
+/* enable != 0: from now on every launch is bracketed by events on its stream. */
+int vfe_prof_enable(int enable);
+/* Synchronise the recorded events, add their durations to the totals, and copy the totals:
+ * ms[VFE_K_COUNT] = summed milliseconds, launches[VFE_K_COUNT] = launch counts.  reset != 0
+ * clears the totals afterwards. */
+int vfe_prof_read(double* ms, long long* launches, int reset);
+const char* vfe_prof_kernel_name(int id);
 
 /* ---- FAST ------------------------------------------------------------------------------ */
 

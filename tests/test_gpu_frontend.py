@@ -83,7 +83,7 @@ def test_good_features_with_seeds(cuda):
     im1 = synth.scene(synth.BASE_SEED, w, h, 1)
     seeds, _ = ora.good_features(im0, 100, 0.01, d)
     rxy, _ = ora.good_features(im1, n - len(seeds), 0.01, d, seeds=seeds)
-    gf = capi.GoodFeatures(1, h, w, n - len(seeds), seed_cap=128, device=cuda)
+    gf = capi.GoodFeatures(1, h, w, n, seed_cap=128, device=cuda)  # refill: n - len(seeds) new corners
     sd = torch.zeros((1, 128, 2), dtype=torch.float32, device=cuda)
     sd[0, :len(seeds)] = torch.from_numpy(seeds).to(cuda)
     ns = torch.tensor([len(seeds)], dtype=torch.int32, device=cuda)
@@ -132,3 +132,46 @@ def test_klt_parity(cuda, w, h, levels, npts):
         # the scene moves by (-1.5, -0.75) px/frame plus a small rotation: flow must be close to that
         flow = (ro - pts[i])[good]
         assert np.abs(np.median(flow, axis=0) - [-1.5, -0.75]).max() < 0.5
+
+
+def _oracle_step(prev, cur, pts, n, q, d, levels, w, h):
+    nxt, st, _ = ora.klt_track(prev, cur, pts, 21, levels - 1)
+    r = np.rint(nxt)
+    keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < w - 1) & (r[:, 1] >= 1) & (r[:, 1] < h - 1)
+    tracked = nxt[keep]
+    if n - len(tracked) > 0:
+        new, _ = ora.good_features(cur, n - len(tracked), q, d, seeds=tracked)
+        return (np.concatenate([tracked, new]) if len(new) else tracked), len(tracked)
+    return tracked, len(tracked)
+
+
+@pytest.mark.parametrize("w,h,n,d,levels", [(752, 480, 150, 30, 3), (640, 360, 300, 12, 4)])
+def test_frontend_step_sequence(cuda, w, h, n, d, levels):
+    """Three consecutive steps of two streams: tracked + refilled point sets equal the oracle's."""
+    import torch
+    q = 0.01
+    seeds = [synth.BASE_SEED + 10, synth.BASE_SEED + 11]
+    seq = [[synth.scene(s, w, h, t) for t in range(4)] for s in seeds]
+    B = len(seq)
+    fe = capi.FrontendStep(B, h, w, n, levels, 21, quality=q, min_distance=d, device=cuda)
+    frames = [to_dev([seq[b][t] for b in range(B)], cuda) for t in range(4)]
+    pyr = [capi.alloc_pyramid(frames[0], levels), capi.alloc_pyramid(frames[0], levels)]
+    capi.build_pyramid(pyr[0])
+    ref = []
+    for b in range(B):
+        xy, _ = ora.good_features(seq[b][0], n, q, d)
+        ref.append(xy)
+        fe.pts[b, :len(xy)] = torch.from_numpy(xy).to(cuda)
+        fe.n_pts[b] = len(xy)
+    cur = 0
+    for t in range(1, 4):
+        nxt = cur ^ 1
+        pyr[nxt][0] = frames[t]
+        pts, n_pts, n_tr = fe.step(pyr[cur], pyr[nxt])
+        cur = nxt
+        pts, n_pts, n_tr = pts.cpu().numpy(), n_pts.cpu().numpy(), n_tr.cpu().numpy()
+        for b in range(B):
+            ref[b], ntr = _oracle_step(seq[b][t - 1], seq[b][t], ref[b], n, q, d, levels, w, h)
+            assert n_tr[b] == ntr and n_pts[b] == len(ref[b]), f"t={t} b={b}: {n_tr[b]}/{n_pts[b]} vs {ntr}/{len(ref[b])}"
+            assert np.array_equal(pts[b, :n_pts[b]].view(np.uint32), ref[b].view(np.uint32)), f"t={t} b={b}"
+            assert ntr > 0.8 * n

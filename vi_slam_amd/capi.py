@@ -64,6 +64,14 @@ SIGNATURES = {
     "vfe_dev_min_eigen_map": (C.c_int, [_DI, _P, _P]),
     "vfe_dev_klt_track": (C.c_int, [_DI, _DI, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_double,
                                     C.c_double, C.c_int, _P]),
+    "vfe_dev_compact_tracks": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "vfe_dev_append_points": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
+    "vfe_frontend_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfe_dev_frontend_step": (C.c_int, [_DI, _DI, C.c_int, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int,
+                                        C.c_int, C.c_double, C.c_double, _P, C.c_size_t, _P]),
+    "vfe_prof_enable": (C.c_int, [C.c_int]),
+    "vfe_prof_read": (C.c_int, [_P, _P, C.c_int]),
+    "vfe_prof_kernel_name": (C.c_char_p, [C.c_int]),
     "vfe_fast_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "vfe_dev_fast9": (C.c_int, [_DI, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "vfe_dev_fast_grid": (C.c_int, [_DI, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P,
@@ -218,3 +226,58 @@ def klt_track(prev_levels, next_levels, prev_pts, n_pts=None, next_pts=None, sta
     check(lib().vfe_dev_klt_track(pa, na, n, _ptr(prev_pts), _ptr(n_pts), cap, _ptr(next_pts), _ptr(status),
                                   _ptr(err), win, max_iter, eps, min_eig_thr, 1 if use_initial_flow else 0, _stream()))
     return next_pts, status, err
+
+
+def compact_tracks(pts, status, n_pts, width, height, border=1):
+    import torch
+    b, cap, _ = pts.shape
+    out = torch.zeros_like(pts)
+    out_n = torch.zeros(b, dtype=torch.int32, device=pts.device)
+    check(lib().vfe_dev_compact_tracks(_ptr(pts), _ptr(status), _ptr(n_pts), cap, b, width, height, border,
+                                       _ptr(out), _ptr(out_n), _stream()))
+    return out, out_n
+
+
+class FrontendStep:
+    """Buffers + call wrapper for vfe_dev_frontend_step on `batch` streams of h x w frames."""
+
+    def __init__(self, batch, h, w, max_corners, nlevels=4, win=21, max_iter=30, eps=0.01, min_eig_thr=1e-4,
+                 quality=0.01, min_distance=20.0, device="cuda"):
+        import torch
+        self.batch, self.h, self.w, self.cap, self.nlevels = batch, h, w, max_corners, nlevels
+        self.win, self.max_iter, self.eps, self.min_eig_thr = win, max_iter, eps, min_eig_thr
+        self.quality, self.min_distance = quality, min_distance
+        nbytes = lib().vfe_frontend_workspace(w, h, batch, max_corners)
+        if nbytes == 0:
+            raise VfeError("vfe_frontend_workspace: invalid shape")
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.ws_bytes = nbytes
+        self.pts = torch.zeros((batch, max_corners, 2), dtype=torch.float32, device=device)
+        self.n_pts = torch.zeros(batch, dtype=torch.int32, device=device)
+        self.n_tracked = torch.zeros(batch, dtype=torch.int32, device=device)
+
+    def step(self, prev_levels, next_levels):
+        n = self.nlevels
+        pa = (DImg * n)(*[dimg(t) for t in prev_levels])
+        na = (DImg * n)(*[dimg(t) for t in next_levels])
+        check(lib().vfe_dev_frontend_step(pa, na, n, _ptr(self.pts), _ptr(self.n_pts), _ptr(self.n_tracked), self.cap,
+                                          self.quality, self.min_distance, self.win, self.max_iter, self.eps,
+                                          self.min_eig_thr, _ptr(self.ws), self.ws_bytes, _stream()))
+        return self.pts, self.n_pts, self.n_tracked
+
+
+K_NAMES = None
+
+
+def prof_enable(on=True):
+    check(lib().vfe_prof_enable(1 if on else 0))
+
+
+def prof_read(reset=True):
+    """{kernel name: (total ms, launches)} for every kernel launched since the last reset."""
+    L = lib()
+    n = 13
+    ms = (C.c_double * n)()
+    cnt = (C.c_longlong * n)()
+    check(L.vfe_prof_read(ms, cnt, 1 if reset else 0))
+    return {L.vfe_prof_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}

@@ -2,6 +2,8 @@
 #include "vfe_common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -39,4 +41,69 @@ extern "C" int vfe_device_count(int* count) {
     }
     *count = n;
     return VFE_OK;
+}
+
+/* ---- kernel timing --------------------------------------------------------------------- */
+int g_vfe_prof_on = 0;
+namespace {
+struct ProfRec { int id; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_open;            /* begin recorded, end pending (per thread use is sequential) */
+std::vector<ProfRec> g_prof_done;
+std::vector<hipEvent_t> g_prof_pool;
+double g_prof_ms[VFE_K_COUNT];
+long long g_prof_n[VFE_K_COUNT];
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+void vfe_prof_begin(int id, hipStream_t st) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    ProfRec r; r.id = id; r.a = prof_event(); r.b = prof_event();
+    if (!r.a || !r.b) return;
+    (void)hipEventRecord(r.a, st);
+    g_prof_open.push_back(r);
+}
+void vfe_prof_end(int id, hipStream_t st) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    for (size_t i = g_prof_open.size(); i-- > 0;)
+        if (g_prof_open[i].id == id) {
+            ProfRec r = g_prof_open[i];
+            g_prof_open.erase(g_prof_open.begin() + i);
+            (void)hipEventRecord(r.b, st);
+            g_prof_done.push_back(r);
+            return;
+        }
+}
+
+extern "C" int vfe_prof_enable(int enable) { g_vfe_prof_on = enable ? 1 : 0; return VFE_OK; }
+
+extern "C" int vfe_prof_read(double* ms, long long* launches, int reset) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    for (auto& r : g_prof_done) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess &&
+            r.id >= 0 && r.id < VFE_K_COUNT) {
+            g_prof_ms[r.id] += t; g_prof_n[r.id] += 1;
+        }
+        g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b);
+    }
+    g_prof_done.clear();
+    for (int i = 0; i < VFE_K_COUNT; i++) {
+        if (ms) ms[i] = g_prof_ms[i];
+        if (launches) launches[i] = g_prof_n[i];
+        if (reset) { g_prof_ms[i] = 0; g_prof_n[i] = 0; }
+    }
+    return VFE_OK;
+}
+
+extern "C" const char* vfe_prof_kernel_name(int id) {
+    static const char* names[VFE_K_COUNT] = {"k_pyr_down", "k_gftt_eig", "k_gftt_select", "k_klt", "k_compact",
+                                             "k_append", "k_fast", "k_orb_resize", "k_orb_blur", "k_orb_select",
+                                             "k_orb_desc", "k_match", "misc"};
+    return (id >= 0 && id < VFE_K_COUNT) ? names[id] : "?";
 }

@@ -36,6 +36,17 @@ void vfe_set_error(const char* fmt, ...);
         }                                                                                  \
     } while (0)
 
+/* kernel timing: when enabled (vfe_prof_enable), every launch site brackets its kernel with
+ * a pair of HIP events on the launch stream */
+extern int g_vfe_prof_on;
+void vfe_prof_begin(int id, hipStream_t st);
+void vfe_prof_end(int id, hipStream_t st);
+struct ProfScope {
+    int id; hipStream_t st; bool on;
+    ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on(g_vfe_prof_on != 0) { if (on) vfe_prof_begin(id, st); }
+    ~ProfScope() { if (on) vfe_prof_end(id, st); }
+};
+
 /* plain-data view of one batched image, passed to kernels by value */
 struct DImg {
     uint8_t* data;

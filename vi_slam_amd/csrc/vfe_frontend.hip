@@ -1,0 +1,124 @@
+/* Batched steady-state front-end step: pyramid -> KLT -> drop lost tracks -> Shi-Tomasi refill.
+ * The batched form of what a framework adapter does in one processImage call
+ * (reference call path: src/slam/slam_engine.cpp:94-119 -> adapters' feedImage). */
+#include "vfe_common.h"
+
+/* stable compaction of surviving tracks, one workgroup per stream */
+__global__ __launch_bounds__(256) void k_compact(const float* __restrict__ pts, const uint8_t* __restrict__ status,
+                                                 const int* __restrict__ n_pts, int cap, int W, int H, int border,
+                                                 float* __restrict__ out, int* __restrict__ out_n) {
+    __shared__ int s_w[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = n_pts ? max(0, min(n_pts[b], cap)) : cap;
+    int base = 0;
+    for (int start = 0; start < n; start += 256) {
+        const int i = start + tid;
+        bool keep = false;
+        float x = 0.f, y = 0.f;
+        if (i < n && status[(size_t)b * cap + i]) {
+            x = pts[((size_t)b * cap + i) * 2]; y = pts[((size_t)b * cap + i) * 2 + 1];
+            const int ix = __float2int_rn(x), iy = __float2int_rn(y);
+            keep = ix >= border && ix < W - border && iy >= border && iy < H - border;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wv] = __popcll(m);
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (k < wv) off += s_w[k]; tot += s_w[k]; }
+        /* in-place use (out == pts) is safe: element base+off+pre <= i and each chunk is read before it is written */
+        __syncthreads();
+        if (keep) {
+            out[((size_t)b * cap + base + off + pre) * 2] = x;
+            out[((size_t)b * cap + base + off + pre) * 2 + 1] = y;
+        }
+        base += tot;
+    }
+    if (tid == 0) out_n[b] = base;
+}
+
+__global__ __launch_bounds__(256) void k_append(float* __restrict__ pts, int* __restrict__ n_pts, int cap,
+                                                const float* __restrict__ extra, const int* __restrict__ n_extra,
+                                                int extra_cap) {
+    const int b = blockIdx.x;
+    const int n0 = max(0, min(n_pts[b], cap));
+    const int ne = max(0, min(min(n_extra[b], extra_cap), cap - n0));
+    for (int i = threadIdx.x; i < ne; i += 256) {
+        pts[((size_t)b * cap + n0 + i) * 2] = extra[((size_t)b * extra_cap + i) * 2];
+        pts[((size_t)b * cap + n0 + i) * 2 + 1] = extra[((size_t)b * extra_cap + i) * 2 + 1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) n_pts[b] = n0 + ne;
+}
+
+extern "C" int vfe_dev_compact_tracks(const float* pts, const uint8_t* status, const int* n_pts, int cap, int batch,
+                                      int width, int height, int border, float* out_pts, int* out_n, void* stream) {
+    VFE_REQUIRE(pts && status && out_pts && out_n, "NULL buffer");
+    VFE_REQUIRE(cap > 0 && batch > 0 && width > 0 && height > 0 && border >= 0, "bad sizes");
+    VFE_REQUIRE(out_pts != pts, "compaction is out of place");
+    ProfScope prof(VFE_K_COMPACT, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, (hipStream_t)stream, pts, status, n_pts, cap, width, height,
+                       border, out_pts, out_n);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
+extern "C" int vfe_dev_append_points(float* pts, int* n_pts, int cap, int batch,
+                                     const float* extra, const int* n_extra, int extra_cap, void* stream) {
+    VFE_REQUIRE(pts && n_pts && extra && n_extra, "NULL buffer");
+    VFE_REQUIRE(cap > 0 && batch > 0 && extra_cap > 0, "bad sizes");
+    ProfScope prof(VFE_K_APPEND, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_append, dim3(batch), dim3(256), 0, (hipStream_t)stream, pts, n_pts, cap, extra, n_extra, extra_cap);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
+struct FeWs { size_t gf_off, gf_bytes, next_off, status_off, corners_off, counts_off, total; };
+
+static FeWs fe_layout(int w, int h, int batch, int cap) {
+    FeWs L; size_t o = 0;
+    L.gf_off = o; L.gf_bytes = vfe_good_features_workspace(w, h, batch, cap, cap); o += align_up(L.gf_bytes, 256);
+    L.next_off = o; o += align_up((size_t)batch * cap * 2 * sizeof(float), 256);
+    L.status_off = o; o += align_up((size_t)batch * cap, 256);
+    L.corners_off = o; o += align_up((size_t)batch * cap * 2 * sizeof(float), 256);
+    L.counts_off = o; o += align_up((size_t)batch * sizeof(int), 256);
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t vfe_frontend_workspace(int width, int height, int batch, int max_corners) {
+    if (width <= 0 || height <= 0 || batch <= 0 || max_corners <= 0) return 0;
+    return fe_layout(width, height, batch, max_corners).total;
+}
+
+extern "C" int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                                     float* pts, int* n_pts, int* n_tracked, int max_corners,
+                                     double quality, double min_distance,
+                                     int win, int max_iter, double eps, double min_eig_thr,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    VFE_REQUIRE(prev_levels && next_levels && nlevels >= 1 && nlevels <= 8, "nlevels must be 1..8");
+    VFE_REQUIRE(pts && n_pts && workspace, "NULL buffer");
+    VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+    int rc = vfe_check_dimg(&next_levels[0], "next level 0");
+    if (rc) return rc;
+    const int w = next_levels[0].width, h = next_levels[0].height, batch = next_levels[0].batch, cap = max_corners;
+    const FeWs L = fe_layout(w, h, batch, cap);
+    if (workspace_bytes < L.total) {
+        vfe_set_error("workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+        return VFE_E_NOMEM;
+    }
+    char* ws = (char*)workspace;
+    float* next_pts = (float*)(ws + L.next_off);
+    uint8_t* status = (uint8_t*)(ws + L.status_off);
+    float* corners = (float*)(ws + L.corners_off);
+    int* counts = (int*)(ws + L.counts_off);
+    if ((rc = vfe_dev_build_pyramid(next_levels, nlevels, stream))) return rc;
+    if ((rc = vfe_dev_klt_track(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
+                                win, max_iter, eps, min_eig_thr, 0, stream))) return rc;
+    if ((rc = vfe_dev_compact_tracks(next_pts, status, n_pts, cap, batch, w, h, 1, pts, n_pts, stream))) return rc;
+    if (n_tracked) VFE_HIP(hipMemcpyAsync(n_tracked, n_pts, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if ((rc = vfe_dev_good_features(&next_levels[0], cap, quality, min_distance, pts, n_pts, cap, corners, nullptr, counts,
+                                    ws + L.gf_off, L.gf_bytes, stream))) return rc;
+    return vfe_dev_append_points(pts, n_pts, cap, batch, corners, counts, cap, stream);
+}

@@ -212,9 +212,11 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     u32* node_next = p.node_next + (size_t)b * p.node_cap;
 
     if (tid == 0) { s_cnt = 0; s_nacc = 0; }
+    /* refill budget: tracked points count towards max_corners */
+    const int ns = (p.seeds && p.n_seeds) ? max(0, min(p.n_seeds[b], p.seed_cap)) : 0;
+    const int limit = max(0, p.max_corners - ns);
     /* tracked points occupy the grid first */
-    if (p.use_grid && p.seeds && p.n_seeds) {
-        const int ns = min(p.n_seeds[b], p.seed_cap);
+    if (p.use_grid && ns > 0) {
         const float* sd = p.seeds + (size_t)b * p.seed_cap * 2;
         for (int s = tid; s < ns; s += SEL_THREADS) {
             const int sx = __float2int_rn(sd[2 * s]), sy = __float2int_rn(sd[2 * s + 1]);
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     u64 U = ~0ull; /* exclusive upper bound of keys not yet consumed */
     u32 consumed = 0;
     int n_acc = 0;
-    while (consumed < total && n_acc < p.max_corners) {
+    while (consumed < total && n_acc < limit) {
         u64 T;
         if (total - consumed <= SEL_M) {
             T = lowkey + 1;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
         if (tid < 64) {
             const int lane = tid;
             int acc = s_nacc;
-            for (u32 base = 0; base < taken && acc < p.max_corners; base += 64) {
+            for (u32 base = 0; base < taken && acc < limit; base += 64) {
                 const u32 i = base + lane;
                 const bool valid = i < taken;
                 const u64 key = valid ? s_keys[i] : 0ull;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                     }
                 }
                 u64 mask = __ballot(alive);
-                while (mask && acc < p.max_corners) {
+                while (mask && acc < limit) {
                     const int l = __ffsll((long long)mask) - 1;
                     const int ax = __shfl(x, l), ay = __shfl(y, l);
                     if (lane == l) {
@@ -445,8 +447,11 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     const u32 cand_cap = (u32)((size_t)img->width * img->height);
     DImg d = to_dimg(img);
     dim3 grid(div_up(d.w, GF_TW), div_up(d.h, GF_TH), d.batch);
-    hipLaunchKernelGGL(k_gftt_eig<false>, grid, dim3(256), 0, st, d, (float*)nullptr, frame_max, cand_count,
-                       (u64*)(ws + L.cand_off), cand_cap, quality);
+    {
+        ProfScope prof(VFE_K_GFTT_EIG, st);
+        hipLaunchKernelGGL(k_gftt_eig<false>, grid, dim3(256), 0, st, d, (float*)nullptr, frame_max, cand_count,
+                           (u64*)(ws + L.cand_off), cand_cap, quality);
+    }
     VFE_LAUNCH_CHECK();
     SelParams p;
     p.W = d.w; p.H = d.h; p.max_corners = max_corners; p.quality = quality;
@@ -457,7 +462,10 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     p.node_cap = L.node_cap;
     p.seeds = seeds_xy; p.n_seeds = n_seeds; p.seed_cap = seed_cap;
     p.corners = corners_xy; p.scores = scores; p.counts = counts;
-    hipLaunchKernelGGL(k_gftt_select, dim3(d.batch), dim3(SEL_THREADS), 0, st, p);
+    {
+        ProfScope prof(VFE_K_GFTT_SELECT, st);
+        hipLaunchKernelGGL(k_gftt_select, dim3(d.batch), dim3(SEL_THREADS), 0, st, p);
+    }
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }

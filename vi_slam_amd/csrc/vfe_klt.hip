@@ -232,6 +232,7 @@ extern "C" int vfe_dev_klt_track(const vfe_dimg* prev_levels, const vfe_dimg* ne
     p.use_initial = use_initial_flow ? 1 : 0;
     const int PW = win + 3, DW = win + 1;
     const size_t smem = ((PW * PW + 15) & ~15) + (size_t)DW * DW * 4 + (size_t)((win * win + 1) & ~1) * 2 + (size_t)win * win * 4;
+    ProfScope prof(VFE_K_KLT, (hipStream_t)stream);
     hipLaunchKernelGGL(k_klt, dim3(pts_cap, prev_levels[0].batch), dim3(64), smem, (hipStream_t)stream, p);
     VFE_LAUNCH_CHECK();
     return VFE_OK;

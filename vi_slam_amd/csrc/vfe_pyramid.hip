@@ -92,6 +92,7 @@ static bool dword_ok(const DImg& d) {
 
 static int launch_pyr_down(const DImg& s, const DImg& d, hipStream_t st) {
     dim3 grid(div_up(d.w, PD_TW), div_up(d.h, PD_TH), d.batch);
+    ProfScope prof(VFE_K_PYR_DOWN, st);
     if (dword_ok(s) && dword_ok(d))
         hipLaunchKernelGGL(k_pyr_down<true>, grid, dim3(256), 0, st, s, d);
     else
