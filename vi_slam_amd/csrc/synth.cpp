@@ -10,6 +10,7 @@
 #include <cmath>
 #include <vector>
 #include <cstring>
+#include <algorithm>
 
 namespace {
 
@@ -19,7 +20,7 @@ inline uint32_t mix32(uint32_t h) {
 inline uint32_t hash2(uint32_t seed, uint32_t idx) { return mix32(seed ^ mix32(idx + 0x9E3779B9u)); }
 
 /* Static toroidal world: 4 octaves of value noise (cells 64/32/16/8 px, weights 8:4:2:1)
- * with 256 axis-aligned rectangles of random grey painted on top. */
+ * with axis-aligned rectangles of random grey painted on top (one per 1536 px^2, at least 256). */
 struct Canvas {
     int cw, ch; std::vector<uint8_t> px;
     Canvas(uint32_t seed, int w, int h) {
@@ -40,7 +41,8 @@ struct Canvas {
                 }
                 px[(size_t)y * cw + x] = (uint8_t)std::floor(acc / 15.0 + 0.5);
             }
-        for (int r = 0; r < 256; r++) {
+        const int n_rect = std::max(256, cw * ch / 1536); /* same rectangle density at every size */
+        for (int r = 0; r < n_rect; r++) {
             uint32_t a = hash2(seed + 0x7777u, 4 * r), b = hash2(seed + 0x7777u, 4 * r + 1),
                      c = hash2(seed + 0x7777u, 4 * r + 2), d = hash2(seed + 0x7777u, 4 * r + 3);
             int x0 = a % cw, y0 = b % ch, rw = 8 + (c & 63), rh = 8 + ((c >> 8) & 63);

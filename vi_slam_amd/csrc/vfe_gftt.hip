@@ -26,42 +26,65 @@ typedef unsigned int u32;
 
 #define GF_TW 64
 #define GF_TH 16
-#define GF_IW (GF_TW + 8)
+#define GF_IWB 80            /* staged tile row: 20 dwords; tile byte t <-> image x = ox - 4 + t */
 #define GF_IH (GF_TH + 6)
 #define GF_CW (GF_TW + 4)
 #define GF_CH (GF_TH + 4)
 #define GF_HW (GF_TW + 2)
 #define GF_EH (GF_TH + 2)
+#define GF_MAX_WGS 2048u      /* persistent workgroups: 256 CUs x 8 */
+#define GF_CSTRIDE 64         /* u32 stride between counters: one 256-B line each, so atomics on
+                                different frames / segments go to different L2 channels */
+#define GF_NSEG 8            /* candidate lists per frame (spreads the reservation atomics) */
 
 #define SEL_THREADS 1024
 #define SEL_M 8192
 
-template <bool WRITE_MAP>
-__global__ __launch_bounds__(256) void k_gftt_eig(DImg img, float* __restrict__ eigmap, u32* __restrict__ frame_max,
-                                                  u32* __restrict__ cand_count, u64* __restrict__ cand, u32 cand_cap,
-                                                  double quality) {
-    __shared__ uint8_t s_img[GF_IH][GF_IW];
+/* Workgroup id -> (tile, frame) with the frame index fastest, so that consecutive workgroups
+ * update different frames' counters and maxima. */
+template <bool WRITE_MAP, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int tiles_x, unsigned total_work, float* __restrict__ eigmap,
+                                                  u32* __restrict__ frame_max, u32* __restrict__ cand_count,
+                                                  u64* __restrict__ cand, u32 seg_cap, double quality) {
+    __shared__ __align__(16) uint32_t s_imgw[GF_IH][GF_IWB / 4];
     __shared__ float s_cov[3][GF_CH][GF_CW];
     __shared__ float s_h[3][GF_CH][GF_HW];
     __shared__ float s_eig[GF_EH][GF_HW];
     __shared__ float s_red[4];
     __shared__ float s_prune;
+    __shared__ u32 s_ncand, s_base, s_seen;
+    const uint8_t* s_img = reinterpret_cast<const uint8_t*>(&s_imgw[0][0]);
 
-    const int b = blockIdx.z, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int W = img.w, H = img.h;
+    /* persistent workgroups: a few thousand workgroups stride over all (tile, frame) items,
+     * which costs far less than dispatching one workgroup per tile */
+    for (unsigned work = blockIdx.x; work < total_work; work += gridDim.x) {
+    const int b = work % img.batch, tile = work / img.batch;
     const uint8_t* ip = img.frame(b);
-    const int ox = blockIdx.x * GF_TW, oy = blockIdx.y * GF_TH;
+    const int ox = (tile % tiles_x) * GF_TW, oy = (tile / tiles_x) * GF_TH;
 
-    if (!WRITE_MAP && tid == 0) {
-        u32 rm = __hip_atomic_load(&frame_max[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_prune = (float)((double)__uint_as_float(rm) * quality);
+    if (tid == 0) {
+        s_ncand = 0;
+        if (!WRITE_MAP) {
+            const u32 rm = __hip_atomic_load(&frame_max[b * GF_CSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_seen = rm;
+            s_prune = (float)((double)__uint_as_float(rm) * quality);
+        }
     }
-    for (int i = tid; i < GF_IH * GF_IW; i += 256) {
-        const int ty = i / GF_IW, tx = i - ty * GF_IW;
-        const int gx = ox - 3 + tx, gy = oy - 3 + ty;
-        uint8_t v = 0;
-        if (gx <= W + 2 && gy <= H + 2) v = ip[(size_t)reflect101(gy, H) * img.pitch + reflect101(gx, W)];
-        s_img[ty][tx] = v;
+    for (int i = tid; i < GF_IH * (GF_IWB / 4); i += 256) {
+        const int ty = i / (GF_IWB / 4), k = i - ty * (GF_IWB / 4);
+        const int gx = ox - 4 + 4 * k, gy = oy - 3 + ty;
+        uint32_t v = 0;
+        if (gx <= W + 2 && gy <= H + 2) {
+            const uint8_t* row = ip + (size_t)reflect101(gy, H) * img.pitch;
+            if (ALIGNED && gx >= 0 && gx + 3 < W)
+                v = *reinterpret_cast<const uint32_t*>(row + gx);
+            else
+                v = (uint32_t)row[reflect101(gx, W)] | ((uint32_t)row[reflect101(gx + 1, W)] << 8) |
+                    ((uint32_t)row[reflect101(gx + 2, W)] << 16) | ((uint32_t)row[reflect101(gx + 3, W)] << 24);
+        }
+        s_imgw[ty][k] = v;
     }
     __syncthreads();
 
@@ -74,11 +97,12 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, float* __restrict__ 
         if (px >= -1 && px <= W && py >= -1 && py <= H) {
             /* products live on the image grid; positions outside are the reflection of the
              * product plane, i.e. the gradient taken at the reflected centre */
-            const int tx = reflect101(px, W) - (ox - 3), ty = reflect101(py, H) - (oy - 3);
+            const int tx = reflect101(px, W) - (ox - 4), ty = reflect101(py, H) - (oy - 3);
             float rx[3], ry[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const int a = s_img[ty - 1 + k][tx - 1], m = s_img[ty - 1 + k][tx], c = s_img[ty - 1 + k][tx + 1];
+                const uint8_t* r = s_img + (ty - 1 + k) * GF_IWB + tx;
+                const int a = r[-1], m = r[0], c = r[1];
                 rx[k] = (float)(c - a);
                 ry[k] = k_c * (float)m + k_o * (float)(a + c);
             }
@@ -116,11 +140,14 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, float* __restrict__ 
 
     float bmax = 0.f;
     const float prune = WRITE_MAP ? 0.f : s_prune;
+    u64 mykeys[GF_TW * GF_TH / 256];
+    int nmine = 0;
 #pragma unroll
     for (int k = 0; k < GF_TW * GF_TH / 256; k++) {
         const int i = tid + k * 256;
         const int y = i / GF_TW, x = i - y * GF_TW;
         const int px = ox + x, py = oy + y;
+        mykeys[k] = 0;
         if (px >= W || py >= H) continue;
         const float v = s_eig[y + 1][x + 1];
         if (WRITE_MAP) {
@@ -132,22 +159,37 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, float* __restrict__ 
                 m = fmaxf(m, fmaxf(s_eig[y + 1][x], s_eig[y + 1][x + 2]));
                 m = fmaxf(m, fmaxf(fmaxf(s_eig[y + 2][x], s_eig[y + 2][x + 1]), s_eig[y + 2][x + 2]));
                 if (v >= m) {
-                    const u32 pos = atomicAdd(&cand_count[b], 1u);
-                    if (pos < cand_cap)
-                        cand[(size_t)b * cand_cap + pos] = ((u64)__float_as_uint(v) << 32) | (u32)(py * W + px);
+                    mykeys[k] = ((u64)__float_as_uint(v) << 32) | (u32)(py * W + px);
+                    nmine++;
                 }
             }
         }
     }
     if (!WRITE_MAP) {
+        /* one reservation per workgroup: LDS counter for the local offsets, one global atomic */
+        u32 lpos = 0;
+        if (nmine) lpos = atomicAdd(&s_ncand, (u32)nmine);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o));
         if ((tid & 63) == 0) s_red[tid >> 6] = bmax;
         __syncthreads();
+        const int seg = tile % GF_NSEG;
         if (tid == 0) {
             const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-            if (m > 0.f) atomicMax(&frame_max[b], __float_as_uint(m)); /* positive floats order as uints */
+            /* positive floats order as uints; most tiles cannot raise the maximum already seen */
+            if (m > 0.f && __float_as_uint(m) > s_seen) atomicMax(&frame_max[b * GF_CSTRIDE], __float_as_uint(m));
+            s_base = s_ncand ? atomicAdd(&cand_count[(b * GF_NSEG + seg) * GF_CSTRIDE], s_ncand) : 0u;
         }
+        __syncthreads();
+        if (nmine) {
+            u64* dst = cand + ((size_t)b * GF_NSEG + seg) * seg_cap;
+            u32 pos = s_base + lpos;
+#pragma unroll
+            for (int k = 0; k < GF_TW * GF_TH / 256; k++)
+                if (mykeys[k]) { if (pos < seg_cap) dst[pos] = mykeys[k]; pos++; }
+        }
+    }
+    __syncthreads(); /* LDS tiles are reused by the next work item */
     }
 }
 
@@ -159,7 +201,7 @@ struct SelParams {
     const u32* frame_max;
     const u32* cand_count;
     const u64* cand;
-    u32 cand_cap;
+    u32 seg_cap;     /* keys per candidate segment; GF_NSEG segments per frame */
     u32* heads;      /* [batch][gw*gh], 0 = empty, else node index + 1 */
     u32* node_xy;    /* [batch][node_cap]  x | y << 16 */
     u32* node_next;  /* [batch][node_cap] */
@@ -202,9 +244,18 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     __shared__ int s_nacc;
 
     const int b = blockIdx.x, tid = threadIdx.x;
-    const u32 C = min(p.cand_count[b], p.cand_cap);
-    const u64* keys = p.cand + (size_t)b * p.cand_cap;
-    const float maxv = __uint_as_float(p.frame_max[b]);
+    __shared__ u32 s_segn[GF_NSEG];
+    if (tid < GF_NSEG) s_segn[tid] = min(p.cand_count[(b * GF_NSEG + tid) * GF_CSTRIDE], p.seg_cap);
+    const u64* keys = p.cand + (size_t)b * GF_NSEG * p.seg_cap;
+/* visit every candidate key of this frame */
+#define FOR_EACH_KEY(k)                                              \
+    for (int sg_ = 0; sg_ < GF_NSEG; sg_++) {                         \
+        const u32 cn_ = s_segn[sg_];                                 \
+        const u64* kp_ = keys + (size_t)sg_ * p.seg_cap;             \
+        for (u32 i_ = tid; i_ < cn_; i_ += SEL_THREADS) {            \
+            const u64 k = kp_[i_];
+#define END_EACH_KEY }}
+    const float maxv = __uint_as_float(p.frame_max[b * GF_CSTRIDE]);
     const float thr = (float)((double)maxv * p.quality);
     const u64 lowkey = ((u64)__float_as_uint(thr) << 32) | 0xFFFFFFFFull; /* valid keys are > lowkey */
     u32* heads = p.heads + (size_t)b * p.gw * p.gh;
@@ -231,7 +282,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
 
     /* how many candidates pass the exact threshold */
     u32 mine = 0;
-    for (u32 i = tid; i < C; i += SEL_THREADS) mine += (keys[i] > lowkey) ? 1u : 0u;
+    FOR_EACH_KEY(k) mine += (k > lowkey) ? 1u : 0u; END_EACH_KEY
     const u32 total_valid = block_suffix_scan(mine, s_scan) /* value at tid 0 */;
     __shared__ u32 s_total;
     if (tid == 0) s_total = total_valid;
@@ -256,11 +307,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                 const u32 nb = 1u << bits;
                 for (u32 i = tid; i <= 2048; i += SEL_THREADS) s_hist[i] = 0;
                 __syncthreads();
-                for (u32 i = tid; i < C; i += SEL_THREADS) {
-                    const u64 k = keys[i];
+                FOR_EACH_KEY(k)
                     if (k > lowkey && k < U && (hi_shift == 64 || (k >> hi_shift) == prefix))
                         atomicAdd(&s_hist[(u32)(k >> shift) & (nb - 1)], 1u);
-                }
+                END_EACH_KEY
                 __syncthreads();
                 const u32 h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
                 const u32 ss = block_suffix_scan(h0 + h1, s_scan);
@@ -290,13 +340,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
             if (T <= lowkey) T = lowkey + 1;
         }
         /* collect [T, U) */
-        for (u32 i = tid; i < C; i += SEL_THREADS) {
-            const u64 k = keys[i];
+        FOR_EACH_KEY(k)
             if (k >= T && k < U) {
                 const u32 pos = atomicAdd(&s_cnt, 1u);
                 if (pos < SEL_M) s_keys[pos] = k;
             }
-        }
+        END_EACH_KEY
         __syncthreads();
         const u32 taken = min(s_cnt, (u32)SEL_M);
         u32 n2 = 64;
@@ -390,6 +439,7 @@ struct GfWs {
     size_t hdr_off, heads_off, cand_off, nxy_off, nnext_off, total;
     size_t zero_bytes; /* [hdr_off, hdr_off + zero_bytes) is cleared every call */
     int cell, gw, gh, use_grid, node_cap;
+    u32 seg_cap;
 };
 
 static GfWs gf_layout(int w, int h, int batch, int max_corners, int seed_cap, double min_distance) {
@@ -401,10 +451,11 @@ static GfWs gf_layout(int w, int h, int batch, int max_corners, int seed_cap, do
     L.gh = L.use_grid ? (h + L.cell - 1) / L.cell : 1;
     L.node_cap = seed_cap + max_corners;
     size_t o = 0;
-    L.hdr_off = o; o += align_up((size_t)batch * 2 * sizeof(u32), 256);
+    L.hdr_off = o; o += align_up((size_t)batch * (1 + GF_NSEG) * GF_CSTRIDE * sizeof(u32), 256);
     L.heads_off = o; o += align_up((size_t)batch * L.gw * L.gh * sizeof(u32), 256);
     L.zero_bytes = o;
-    L.cand_off = o; o += align_up((size_t)batch * w * h * sizeof(u64), 256);
+    L.seg_cap = (u32)div_up(div_up(w, GF_TW) * div_up(h, GF_TH), GF_NSEG) * (GF_TW * GF_TH);
+    L.cand_off = o; o += align_up((size_t)batch * GF_NSEG * L.seg_cap * sizeof(u64), 256);
     L.nxy_off = o; o += align_up((size_t)batch * L.node_cap * sizeof(u32), 256);
     L.nnext_off = o; o += align_up((size_t)batch * L.node_cap * sizeof(u32), 256);
     L.total = o;
@@ -443,21 +494,28 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     char* ws = (char*)workspace;
     VFE_HIP(hipMemsetAsync(ws + L.hdr_off, 0, L.zero_bytes, st));
     u32* frame_max = (u32*)(ws + L.hdr_off);
-    u32* cand_count = frame_max + img->batch;
-    const u32 cand_cap = (u32)((size_t)img->width * img->height);
+    u32* cand_count = frame_max + (size_t)img->batch * GF_CSTRIDE;
     DImg d = to_dimg(img);
-    dim3 grid(div_up(d.w, GF_TW), div_up(d.h, GF_TH), d.batch);
+    const int tiles_x = div_up(d.w, GF_TW), tiles_y = div_up(d.h, GF_TH);
+    VFE_REQUIRE((long long)tiles_x * tiles_y * d.batch < (1ll << 31), "too many tiles");
+    const unsigned total_work = (unsigned)(tiles_x * tiles_y * d.batch);
+    dim3 grid(total_work < GF_MAX_WGS ? total_work : GF_MAX_WGS);
+    const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
     {
         ProfScope prof(VFE_K_GFTT_EIG, st);
-        hipLaunchKernelGGL(k_gftt_eig<false>, grid, dim3(256), 0, st, d, (float*)nullptr, frame_max, cand_count,
-                           (u64*)(ws + L.cand_off), cand_cap, quality);
+        if (aligned)
+            hipLaunchKernelGGL((k_gftt_eig<false, true>), grid, dim3(256), 0, st, d, tiles_x, total_work, (float*)nullptr, frame_max,
+                               cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality);
+        else
+            hipLaunchKernelGGL((k_gftt_eig<false, false>), grid, dim3(256), 0, st, d, tiles_x, total_work, (float*)nullptr, frame_max,
+                               cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality);
     }
     VFE_LAUNCH_CHECK();
     SelParams p;
     p.W = d.w; p.H = d.h; p.max_corners = max_corners; p.quality = quality;
     p.use_grid = L.use_grid; p.cell = L.cell; p.gw = L.gw; p.gh = L.gh;
     p.md2i = (u32)ceil(min_distance * min_distance);
-    p.frame_max = frame_max; p.cand_count = cand_count; p.cand = (const u64*)(ws + L.cand_off); p.cand_cap = cand_cap;
+    p.frame_max = frame_max; p.cand_count = cand_count; p.cand = (const u64*)(ws + L.cand_off); p.seg_cap = L.seg_cap;
     p.heads = (u32*)(ws + L.heads_off); p.node_xy = (u32*)(ws + L.nxy_off); p.node_next = (u32*)(ws + L.nnext_off);
     p.node_cap = L.node_cap;
     p.seeds = seeds_xy; p.n_seeds = n_seeds; p.seed_cap = seed_cap;
@@ -476,9 +534,12 @@ extern "C" int vfe_dev_min_eigen_map(const vfe_dimg* img, float* eig, void* stre
     VFE_REQUIRE(img->width >= 8 && img->height >= 8, "image must be at least 8x8");
     VFE_REQUIRE(eig, "eig is NULL");
     DImg d = to_dimg(img);
-    dim3 grid(div_up(d.w, GF_TW), div_up(d.h, GF_TH), d.batch);
-    hipLaunchKernelGGL(k_gftt_eig<true>, grid, dim3(256), 0, (hipStream_t)stream, d, eig, (u32*)nullptr, (u32*)nullptr,
-                       (u64*)nullptr, 0u, 0.0);
+    const int tiles_x = div_up(d.w, GF_TW), tiles_y = div_up(d.h, GF_TH);
+    const unsigned total_work = (unsigned)(tiles_x * tiles_y * d.batch);
+    dim3 grid(total_work < GF_MAX_WGS ? total_work : GF_MAX_WGS);
+    ProfScope prof(VFE_K_MISC, (hipStream_t)stream);
+    hipLaunchKernelGGL((k_gftt_eig<true, false>), grid, dim3(256), 0, (hipStream_t)stream, d, tiles_x, total_work, eig, (u32*)nullptr,
+                       (u32*)nullptr, (u64*)nullptr, 0u, 0.0);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }

@@ -30,6 +30,7 @@ struct KltParams {
     double epsilon; /* squared */
     double min_eig_thr;
     int use_initial;
+    unsigned total_work;
 };
 
 __device__ static inline int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
@@ -49,18 +50,21 @@ __device__ static inline void bilinear_weights(float a, float b, int& w00, int& 
 
 __global__ __launch_bounds__(64) void k_klt(KltParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
-    const int lane = threadIdx.x, pt = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x;
     const int win = p.win, PW = win + 3, DW = win + 1;
     uint8_t* s_patch = smem;                                                    /* PW*PW bytes */
     short2* s_deriv = reinterpret_cast<short2*>(smem + ((PW * PW + 15) & ~15)); /* DW*DW */
     short* s_I = reinterpret_cast<short*>(s_deriv + DW * DW);                   /* win*win */
     short2* s_dI = reinterpret_cast<short2*>(s_I + ((win * win + 1) & ~1));     /* win*win */
 
+    /* persistent single-wave workgroups striding over all (frame, point) items */
+    for (unsigned work = blockIdx.x; work < p.total_work; work += gridDim.x) {
+    const int b = work / (unsigned)p.cap, pt = work - (unsigned)b * (unsigned)p.cap;
     const size_t o = (size_t)b * p.cap + pt;
     const int n = p.n_pts ? min(p.n_pts[b], p.cap) : p.cap;
     if (pt >= n) {
         if (lane == 0) { p.status[o] = 0; if (p.err) p.err[o] = 0.f; }
-        return;
+        continue;
     }
     const float ppx = p.prev_pts[2 * o], ppy = p.prev_pts[2 * o + 1];
     float outx = p.use_initial ? p.next_pts[2 * o] : 0.f, outy = p.use_initial ? p.next_pts[2 * o + 1] : 0.f;
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(64) void k_klt(KltParams p) {
         p.status[o] = (uint8_t)status;
         if (p.err) p.err[o] = errv;
     }
+    }
 }
 
 extern "C" int vfe_dev_klt_track(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
@@ -233,7 +238,9 @@ extern "C" int vfe_dev_klt_track(const vfe_dimg* prev_levels, const vfe_dimg* ne
     const int PW = win + 3, DW = win + 1;
     const size_t smem = ((PW * PW + 15) & ~15) + (size_t)DW * DW * 4 + (size_t)((win * win + 1) & ~1) * 2 + (size_t)win * win * 4;
     ProfScope prof(VFE_K_KLT, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_klt, dim3(pts_cap, prev_levels[0].batch), dim3(64), smem, (hipStream_t)stream, p);
+    VFE_REQUIRE((long long)pts_cap * prev_levels[0].batch < (1ll << 31), "too many points");
+    p.total_work = (unsigned)pts_cap * (unsigned)prev_levels[0].batch;
+    hipLaunchKernelGGL(k_klt, dim3(p.total_work < 8192u ? p.total_work : 8192u), dim3(64), smem, (hipStream_t)stream, p);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }

@@ -15,13 +15,16 @@
 #define PD_IN_DW (2 * PD_TW / 4 + 2)
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void k_pyr_down(DImg src, DImg dst) {
+__global__ __launch_bounds__(256) void k_pyr_down(DImg src, DImg dst, int tiles_x, unsigned tiles_per_frame, unsigned total_work) {
     __shared__ __align__(16) uint32_t s_in[PD_IN_ROWS][PD_IN_DW];
     __shared__ __align__(16) uint16_t s_h[PD_IN_ROWS][PD_TW];
-    const int b = blockIdx.z;
+    /* persistent workgroups striding over (frame, tile) items: dispatching one workgroup per
+     * tile costs more than the tile's work */
+    for (unsigned work = blockIdx.x; work < total_work; work += gridDim.x) {
+    const int b = work / tiles_per_frame, tile = work - b * tiles_per_frame;
     const uint8_t* sp = src.frame(b);
     uint8_t* dp = dst.frame(b);
-    const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
+    const int ox = (tile % tiles_x) * PD_TW, oy = (tile / tiles_x) * PD_TH;
     const int gx0 = 2 * ox - 4, gy0 = 2 * oy - 2;
 
     for (int i = threadIdx.x; i < PD_IN_ROWS * PD_IN_DW; i += 256) {
@@ -84,6 +87,8 @@ __global__ __launch_bounds__(256) void k_pyr_down(DImg src, DImg dst) {
             if (dx + 3 < dst.w) drow[3] = (uint8_t)p3;
         }
     }
+    __syncthreads();
+    }
 }
 
 static bool dword_ok(const DImg& d) {
@@ -91,12 +96,14 @@ static bool dword_ok(const DImg& d) {
 }
 
 static int launch_pyr_down(const DImg& s, const DImg& d, hipStream_t st) {
-    dim3 grid(div_up(d.w, PD_TW), div_up(d.h, PD_TH), d.batch);
+    const int tiles_x = div_up(d.w, PD_TW), tiles_y = div_up(d.h, PD_TH);
+    const unsigned tpf = (unsigned)(tiles_x * tiles_y), total = tpf * (unsigned)d.batch;
+    dim3 grid(total < 2048u ? total : 2048u);
     ProfScope prof(VFE_K_PYR_DOWN, st);
     if (dword_ok(s) && dword_ok(d))
-        hipLaunchKernelGGL(k_pyr_down<true>, grid, dim3(256), 0, st, s, d);
+        hipLaunchKernelGGL(k_pyr_down<true>, grid, dim3(256), 0, st, s, d, tiles_x, tpf, total);
     else
-        hipLaunchKernelGGL(k_pyr_down<false>, grid, dim3(256), 0, st, s, d);
+        hipLaunchKernelGGL(k_pyr_down<false>, grid, dim3(256), 0, st, s, d, tiles_x, tpf, total);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
