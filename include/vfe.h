@@ -192,7 +192,7 @@ int vfe_dev_fast_grid(const vfe_dimg* img, int threshold, int grid_x, int grid_y
 
 /* ---- ORB ------------------------------------------------------------------------------- */
 
-size_t vfe_orb_workspace(int width, int height, int batch, int nfeatures, int nlevels);
+size_t vfe_orb_workspace(int width, int height, int batch, float scale_factor, int nlevels);
 int vfe_orb_level_sizes(int width, int height, float scale_factor, int nlevels, int* wh, float* scales);
 int vfe_orb_quotas(int nfeatures, float scale_factor, int nlevels, int* quota);
 
@@ -211,8 +211,10 @@ int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float scale_factor, 
  * behind `knn_ratio`, docs/reference/15_openvins_smartphone_config.md:105).
  *  out_idx/out_dist [nq][2]; train indices are reported as base_index + row, so a shard of a
  *  larger map reports global indices; absent neighbours: idx -1, dist 0x7fffffff. */
+size_t vfe_match_workspace(int nq, long long nt);
 int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long long nt,
-                       int base_index, int* out_idx, int* out_dist, void* stream);
+                       int base_index, int* out_idx, int* out_dist,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Merge per-shard top-2 lists (as all-gathered from `nshards` ranks, [nshards][nq][2]) into
  * the global top-2 by (dist, idx) -- the order a single scan over the whole map produces. */

@@ -1,0 +1,157 @@
+"""GPU parity (through the C ABI) for FAST, ORB, Hamming kNN and colour conversion against the
+CPU oracle: bit-exact keypoint sets, descriptors and matches."""
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+from vi_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def to_dev(imgs, cuda):
+    import torch
+    imgs = np.stack(imgs)
+    b, h, w = imgs.shape
+    t = capi.alloc_image(b, h, w, cuda)
+    t.copy_(torch.from_numpy(imgs).to(cuda))
+    return t
+
+
+@pytest.mark.parametrize("w,h,thr", [(752, 480, 20), (333, 217, 10), (64, 40, 7), (1920, 1080, 20), (7, 7, 1)])
+def test_fast9_bit_exact(cuda, w, h, thr):
+    imgs = [synth.scene(synth.BASE_SEED + 3, w, h, 0), synth.noise(17, w, h), np.full((h, w), 128, np.uint8)]
+    kps, cnt = capi.fast9(to_dev(imgs, cuda), thr)
+    kps, cnt = kps.cpu().numpy(), cnt.cpu().numpy()
+    for i, im in enumerate(imgs):
+        ref = ora.fast9(im, thr)
+        assert cnt[i] == len(ref), f"frame {i}: {cnt[i]} vs {len(ref)}"
+        assert np.array_equal(kps[i, :cnt[i]], ref), f"frame {i}"
+    assert cnt[2] == 0
+
+
+def test_bgr2gray_bit_exact(cuda):
+    import torch
+    w, h = 641, 479
+    rng = np.random.default_rng(5)
+    bgr = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    d = torch.from_numpy(bgr.reshape(2, h, w * 3)).to(cuda)
+    g = capi.bgr2gray(d).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(g[i], ora.bgr2gray(bgr[i]))
+
+
+def check_orb(cuda, imgs, nfeat, nlevels=8, thr=20):
+    h, w = imgs[0].shape
+    orb = capi.Orb(len(imgs), h, w, nfeat, 1.2, nlevels, thr, device=cuda)
+    orb(to_dev(imgs, cuda))
+    for i, im in enumerate(imgs):
+        rk, rd = ora.orb_extract(im, nfeat, 1.2, nlevels, thr)
+        gk, gd = orb.host_keypoints(i)
+        assert len(gk) == len(rk), f"frame {i}: {len(gk)} vs {len(rk)} keypoints"
+        for f in ("octave", "lx", "ly"):
+            assert np.array_equal(gk[f], rk[f]), f"frame {i}: {f}"
+        for f in ("x", "y", "size", "response", "angle"):
+            assert np.array_equal(gk[f].view(np.uint32), rk[f].view(np.uint32)), \
+                f"frame {i}: {f} differs, max abs {np.abs(gk[f] - rk[f]).max()}"
+        assert np.array_equal(gd, rd), f"frame {i}: {np.count_nonzero((gd != rd).any(axis=1))} descriptors differ"
+    return orb
+
+
+@pytest.mark.parametrize("w,h,nfeat", [(752, 480, 1200), (640, 480, 500), (200, 150, 300)])
+def test_orb_bit_exact(cuda, w, h, nfeat):
+    imgs = [synth.scene(synth.BASE_SEED + 4, w, h, 0), synth.noise(23, w, h), np.full((h, w), 128, np.uint8)]
+    orb = check_orb(cuda, imgs, nfeat)
+    assert int(orb.counts[2]) == 0  # constant frame (tests/test_orbslam3_adapter.cpp:70): no keypoints
+    if w >= 640:
+        assert int(orb.counts[0]) > nfeat // 2
+    assert int(orb.counts[0]) > 0 and int(orb.counts[1]) > 0
+
+
+def test_orb_1080p_2000(cuda):
+    w, h = 1920, 1080
+    check_orb(cuda, [synth.scene(synth.BASE_SEED + 5, w, h, 0)], 2000)
+
+
+def test_orb_quotas_and_sizes_match_oracle():
+    from ctypes import c_float, c_int
+    L = capi.lib()
+    for (w, h, n) in [(752, 480, 2000), (752, 480, 1200), (1920, 1080, 2000), (640, 480, 1000)]:
+        wh = (c_int * 16)()
+        sc = (c_float * 8)()
+        q = (c_int * 8)()
+        assert L.vfe_orb_level_sizes(w, h, 1.2, 8, wh, sc) == 0
+        assert L.vfe_orb_quotas(n, 1.2, 8, q) == 0
+        rwh, rsc = ora.orb_level_sizes(w, h)
+        assert np.array_equal(np.array(list(wh)).reshape(8, 2), rwh)
+        assert np.array_equal(np.array(list(sc), np.float32).view(np.uint32), rsc.view(np.uint32))
+        assert list(q) == list(ora.orb_quotas(n))
+    assert list(ora.orb_quotas(2000)) == [434, 362, 302, 251, 209, 175, 145, 122]
+
+
+@pytest.mark.parametrize("nq,nt", [(2000, 2000), (300, 5000), (64, 1), (5, 0), (257, 70000)])
+def test_match_knn2_bit_exact(cuda, nq, nt):
+    import torch
+    q = synth.descriptors(1, nq)
+    t = synth.descriptors(2, nt) if nt else np.zeros((0, 32), np.uint8)
+    # plant near-duplicates and exact ties
+    for i in range(min(nq, nt, 50)):
+        t[(i * 37) % nt] = synth.flip_bits(100 + i, q[i], i % 20)
+    if nt > 10:
+        t[7] = t[3]
+    idx, dist = capi.match_knn2(torch.from_numpy(q).to(cuda), torch.from_numpy(t).to(cuda) if nt else torch.zeros((0, 32), dtype=torch.uint8, device=cuda), base_index=1000)
+    ridx, rdist = ora.match_knn2(q, t, 1000)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(dist.cpu().numpy(), rdist)
+    good = capi.ratio_test(idx, dist, 0.7).cpu().numpy()
+    assert np.array_equal(good, ora.ratio_test(ridx, rdist, 0.7))
+
+
+def test_match_sharded_merge_equals_single_scan(cuda):
+    """cfg5 shape at reduced size: a map split into 8 contiguous shards, per-shard top-2 merged by
+    (dist, idx) equals one scan over the whole map; planted near-duplicates are found."""
+    import torch
+    nq, nt, S = 500, 80000, 8
+    q = synth.descriptors(11, nq)
+    t = synth.descriptors(synth.MAP_SEED, nt)
+    planted = {}
+    for i in range(200):
+        pos = (i * 397 + 13) % nt
+        t[pos] = synth.flip_bits(i, q[i], i % 21)
+        planted[i] = pos
+    t[100] = t[60000]  # identical descriptors in different shards: lower index must win
+    qd, td = torch.from_numpy(q).to(cuda), torch.from_numpy(t).to(cuda)
+    full_idx, full_dist = capi.match_knn2(qd, td)
+    per = nt // S
+    si, sd = [], []
+    for s in range(S):
+        i_, d_ = capi.match_knn2(qd, td[s * per:(s + 1) * per].contiguous(), base_index=s * per)
+        si.append(i_); sd.append(d_)
+    midx, mdist = capi.merge_knn2(torch.stack(si), torch.stack(sd))
+    assert torch.equal(midx, full_idx) and torch.equal(mdist, full_dist)
+    ridx, rdist = ora.match_knn2(q, t)
+    assert np.array_equal(midx.cpu().numpy(), ridx) and np.array_equal(mdist.cpu().numpy(), rdist)
+    for i, pos in planted.items():
+        assert ridx[i, 0] == pos
+
+
+def test_orb_frame_to_frame_matching(cuda):
+    """cfg3 shape: ORB on consecutive frames + kNN ratio matching; matches agree with the oracle
+    and most of them follow the known scene motion."""
+    import torch
+    w, h = 752, 480
+    f0, f1 = synth.scene(synth.BASE_SEED + 6, w, h, 0), synth.scene(synth.BASE_SEED + 6, w, h, 1)
+    orb = capi.Orb(2, h, w, 1000, device=cuda)
+    orb(to_dev([f0, f1], cuda))
+    k0, d0 = orb.host_keypoints(0)
+    k1, d1 = orb.host_keypoints(1)
+    n0, n1 = len(k0), len(k1)
+    idx, dist = capi.match_knn2(orb.desc[0, :n0].contiguous(), orb.desc[1, :n1].contiguous())
+    good = capi.ratio_test(idx, dist, 0.7).cpu().numpy().astype(bool)
+    ridx, rdist = ora.match_knn2(d0, d1)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dist.cpu().numpy(), rdist)
+    assert good.sum() > 100
+    m = ridx[good, 0]
+    flow = np.stack([k1["x"][m] - k0["x"][good], k1["y"][m] - k0["y"][good]], axis=1)
+    ok = (np.abs(flow - [-1.5, -0.75]) < 3).all(axis=1)
+    assert ok.mean() > 0.8

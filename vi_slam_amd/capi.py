@@ -76,12 +76,13 @@ SIGNATURES = {
     "vfe_dev_fast9": (C.c_int, [_DI, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "vfe_dev_fast_grid": (C.c_int, [_DI, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P,
                                     C.c_int, _P, _P, C.c_size_t, _P]),
-    "vfe_orb_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfe_orb_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
     "vfe_orb_level_sizes": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, _P, _P]),
     "vfe_orb_quotas": (C.c_int, [C.c_int, C.c_float, C.c_int, _P]),
     "vfe_dev_orb_extract": (C.c_int, [_DI, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P,
                                       C.c_size_t, _P]),
-    "vfe_dev_match_knn2": (C.c_int, [_P, C.c_int, _P, C.c_longlong, C.c_int, _P, _P, _P]),
+    "vfe_match_workspace": (C.c_size_t, [C.c_int, C.c_longlong]),
+    "vfe_dev_match_knn2": (C.c_int, [_P, C.c_int, _P, C.c_longlong, C.c_int, _P, _P, _P, C.c_size_t, _P]),
     "vfe_dev_merge_knn2": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "vfe_dev_ratio_test": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P]),
     "vfe_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
@@ -281,3 +282,86 @@ def prof_read(reset=True):
     cnt = (C.c_longlong * n)()
     check(L.vfe_prof_read(ms, cnt, 1 if reset else 0))
     return {L.vfe_prof_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}
+
+
+def bgr2gray(bgr):
+    """bgr: uint8 cuda [B, H, W*3] (rows of interleaved BGR) -> gray [B, H, W]."""
+    b, h, w3 = bgr.shape
+    gray = alloc_image(b, h, w3 // 3, bgr.device)
+    src = DImg(bgr.data_ptr(), w3 // 3, h, bgr.stride(1), b, max(bgr.stride(0), bgr.stride(1) * h))
+    check(lib().vfe_dev_bgr2gray(C.byref(src), C.byref(dimg(gray)), _stream()))
+    return gray
+
+
+def fast9(img, threshold, cap=None):
+    """(kps [B, cap, 3] int32 (x, y, score) in raster order, counts [B])."""
+    import torch
+    b, h, w = img.shape
+    cap = cap or (w * h // 4 + 64)
+    nbytes = lib().vfe_fast_workspace(w, h, b)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=img.device)
+    kps = torch.zeros((b, cap, 3), dtype=torch.int32, device=img.device)
+    counts = torch.zeros(b, dtype=torch.int32, device=img.device)
+    check(lib().vfe_dev_fast9(C.byref(dimg(img)), threshold, _ptr(kps), cap, _ptr(counts), _ptr(ws), nbytes, _stream()))
+    return kps, counts
+
+
+class Orb:
+    """Reusable buffers for vfe_dev_orb_extract on [B, H, W] batches."""
+
+    def __init__(self, batch, h, w, nfeatures, scale_factor=1.2, nlevels=8, fast_threshold=20, cap=None, device="cuda"):
+        import torch
+        self.args = (nfeatures, scale_factor, nlevels, fast_threshold)
+        self.batch, self.h, self.w = batch, h, w
+        self.cap = cap or (2 * nfeatures + 256)
+        nbytes = lib().vfe_orb_workspace(w, h, batch, scale_factor, nlevels)
+        if nbytes == 0:
+            raise VfeError("vfe_orb_workspace: invalid shape")
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.ws_bytes = nbytes
+        self.kps = torch.zeros((batch, self.cap, 8), dtype=torch.int32, device=device)  # 32-byte vfe_orb_kp records
+        self.desc = torch.zeros((batch, self.cap, 32), dtype=torch.uint8, device=device)
+        self.counts = torch.zeros(batch, dtype=torch.int32, device=device)
+
+    def __call__(self, img):
+        assert tuple(img.shape) == (self.batch, self.h, self.w)
+        nf, sf, nl, ft = self.args
+        check(lib().vfe_dev_orb_extract(C.byref(dimg(img)), nf, sf, nl, ft, _ptr(self.kps), _ptr(self.desc), self.cap,
+                                        _ptr(self.counts), _ptr(self.ws), self.ws_bytes, _stream()))
+        return self.kps, self.desc, self.counts
+
+    def host_keypoints(self, b):
+        n = int(self.counts[b])
+        raw = self.kps[b, :n].cpu().numpy()
+        return raw.view(ORB_KP_DTYPE).reshape(n), self.desc[b, :n].cpu().numpy()
+
+
+def match_knn2(query, train, base_index=0):
+    """query [nq, 32], train [nt, 32] uint8 cuda -> (idx [nq, 2], dist [nq, 2]) int32."""
+    import torch
+    nq, nt = query.shape[0], train.shape[0]
+    nbytes = lib().vfe_match_workspace(nq, nt)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=query.device)
+    idx = torch.empty((nq, 2), dtype=torch.int32, device=query.device)
+    dist = torch.empty((nq, 2), dtype=torch.int32, device=query.device)
+    check(lib().vfe_dev_match_knn2(_ptr(query), nq, _ptr(train) if nt else None, nt, base_index, _ptr(idx), _ptr(dist),
+                                   _ptr(ws), nbytes, _stream()))
+    return idx, dist
+
+
+def merge_knn2(shard_idx, shard_dist):
+    """[S, nq, 2] per-shard top-2 lists -> global top-2 by (dist, idx)."""
+    import torch
+    s, nq, _ = shard_idx.shape
+    idx = torch.empty((nq, 2), dtype=torch.int32, device=shard_idx.device)
+    dist = torch.empty((nq, 2), dtype=torch.int32, device=shard_idx.device)
+    check(lib().vfe_dev_merge_knn2(_ptr(shard_idx.contiguous()), _ptr(shard_dist.contiguous()), s, nq, _ptr(idx), _ptr(dist), _stream()))
+    return idx, dist
+
+
+def ratio_test(idx, dist, ratio=0.7):
+    import torch
+    nq = idx.shape[0]
+    good = torch.empty(nq, dtype=torch.uint8, device=idx.device)
+    check(lib().vfe_dev_ratio_test(_ptr(idx), _ptr(dist), nq, ratio, _ptr(good), _stream()))
+    return good

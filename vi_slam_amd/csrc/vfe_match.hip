@@ -1,0 +1,144 @@
+/* Brute-force Hamming kNN (k = 2) on 256-bit descriptors (cv::BFMatcher(NORM_HAMMING).knnMatch
+ * semantics), ratio test and shard merge, for gfx950.
+ *
+ * Integer-VALU bound (8 xor + 8 popcount-accumulate per pair), not HBM bound: each lane keeps
+ * one query descriptor in 8 VGPRs; the train descriptors of a chunk are wave-uniform, so they
+ * are fetched once per wave through the scalar data path and broadcast to all 64 lanes as
+ * SGPR operands.  A workgroup covers 256 queries x one train chunk; per-chunk top-2 lists are
+ * merged by (distance, index), which reproduces the order of one ascending scan with strict
+ * '<' (ties keep the lower train index).
+ */
+#include "vfe_common.h"
+
+typedef unsigned int u32;
+
+#define MT_THREADS 256
+#define NO_IDX (-1)
+#define NO_DIST 0x7fffffff
+
+__device__ static inline void top2_insert(int d, int i, int& d0, int& i0, int& d1, int& i1) {
+    /* lexicographic (dist, idx) order; equals strict-'<' insertion when indices arrive ascending */
+    if (d < d0 || (d == d0 && i < i0)) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
+    else if (d < d1 || (d == d1 && i < i1)) { d1 = d; i1 = i; }
+}
+
+__global__ __launch_bounds__(MT_THREADS) void k_match(const u32* __restrict__ query, int nq,
+                                                     const u32* __restrict__ train, long long nt, int chunk,
+                                                     int nchunks, int base_index,
+                                                     int* __restrict__ part_idx, int* __restrict__ part_dist) {
+    const int q = blockIdx.x * MT_THREADS + threadIdx.x;
+    const int c = blockIdx.y;
+    u32 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = (q < nq) ? query[(size_t)q * 8 + k] : 0u;
+    const long long t0 = (long long)c * chunk;
+    const long long t1 = (t0 + chunk < nt) ? t0 + chunk : nt;
+    int d0 = NO_DIST, d1 = NO_DIST, i0 = NO_IDX, i1 = NO_IDX;
+    for (long long t = t0; t < t1; t++) {
+        const u32* tr = train + (size_t)t * 8; /* wave-uniform address: scalar loads */
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d += __popc(a[k] ^ tr[k]);
+        if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = base_index + (int)t; }
+        else if (d < d1) { d1 = d; i1 = base_index + (int)t; }
+    }
+    if (q < nq) {
+        const size_t o = ((size_t)q * nchunks + c) * 2;
+        part_idx[o] = i0; part_idx[o + 1] = i1;
+        part_dist[o] = d0; part_dist[o + 1] = d1;
+    }
+}
+
+/* merge `nlists` top-2 lists per query; list l of query q at [(q*q_stride + l*l_stride) * 2] */
+__global__ __launch_bounds__(256) void k_merge(const int* __restrict__ in_idx, const int* __restrict__ in_dist,
+                                               int nlists, size_t q_stride, size_t l_stride, int nq,
+                                               int* __restrict__ out_idx, int* __restrict__ out_dist) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    int d0 = NO_DIST, d1 = NO_DIST, i0 = NO_IDX, i1 = NO_IDX;
+    for (int l = 0; l < nlists; l++) {
+        const size_t o = ((size_t)q * q_stride + (size_t)l * l_stride) * 2;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = in_idx[o + k], d = in_dist[o + k];
+            if (i >= 0) top2_insert(d, i, d0, i0, d1, i1);
+        }
+    }
+    out_idx[2 * q] = i0; out_idx[2 * q + 1] = i1;
+    out_dist[2 * q] = d0; out_dist[2 * q + 1] = d1;
+}
+
+__global__ __launch_bounds__(256) void k_ratio(const int* __restrict__ idx, const int* __restrict__ dist, int nq,
+                                               float ratio, uint8_t* __restrict__ good) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    good[q] = (idx[2 * q] >= 0 && idx[2 * q + 1] >= 0 && (float)dist[2 * q] < ratio * (float)dist[2 * q + 1]) ? 1 : 0;
+}
+
+static int match_chunk(int nq, long long nt) {
+    /* enough (query block x chunk) workgroups to fill 256 CUs several times, chunks >= 64 rows */
+    const long long qblocks = (nq + MT_THREADS - 1) / MT_THREADS;
+    long long want = 4096 / (qblocks > 0 ? qblocks : 1);
+    if (want < 1) want = 1;
+    long long chunk = (nt + want - 1) / want;
+    if (chunk < 64) chunk = 64;
+    if (chunk > 65536) chunk = 65536;
+    return (int)chunk;
+}
+
+extern "C" size_t vfe_match_workspace(int nq, long long nt) {
+    if (nq <= 0 || nt < 0) return 0;
+    const int chunk = match_chunk(nq, nt);
+    const long long nchunks = nt > 0 ? (nt + chunk - 1) / chunk : 1;
+    return align_up((size_t)nq * nchunks * 2 * sizeof(int), 256) * 2;
+}
+
+extern "C" int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long long nt,
+                                  int base_index, int* out_idx, int* out_dist,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    VFE_REQUIRE(query && out_idx && out_dist && nq > 0, "NULL buffer or nq <= 0");
+    VFE_REQUIRE(nt >= 0 && (nt == 0 || train), "bad train set");
+    VFE_REQUIRE((long long)base_index + nt <= 0x7fffffffLL, "train indices overflow int");
+    VFE_REQUIRE((uintptr_t)query % 4 == 0 && (uintptr_t)train % 4 == 0, "descriptors must be 4-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunk = match_chunk(nq, nt);
+    const long long nchunks = nt > 0 ? (nt + chunk - 1) / chunk : 1;
+    VFE_REQUIRE(nchunks <= 65535, "train set too large for one call");
+    const size_t need = vfe_match_workspace(nq, nt);
+    if (!workspace || workspace_bytes < need) {
+        vfe_set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+        return VFE_E_NOMEM;
+    }
+    VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+    int* part_idx = (int*)workspace;
+    int* part_dist = (int*)((char*)workspace + need / 2);
+    {
+        ProfScope prof(VFE_K_MATCH, st);
+        hipLaunchKernelGGL(k_match, dim3((nq + MT_THREADS - 1) / MT_THREADS, (unsigned)nchunks), dim3(MT_THREADS), 0, st,
+                           (const u32*)query, nq, (const u32*)train, nt, chunk, (int)nchunks, base_index, part_idx, part_dist);
+    }
+    VFE_LAUNCH_CHECK();
+    ProfScope prof(VFE_K_MISC, st);
+    hipLaunchKernelGGL(k_merge, dim3((nq + 255) / 256), dim3(256), 0, st, part_idx, part_dist, (int)nchunks,
+                       (size_t)nchunks, (size_t)1, nq, out_idx, out_dist);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
+extern "C" int vfe_dev_merge_knn2(const int* shard_idx, const int* shard_dist, int nshards, int nq,
+                                  int* out_idx, int* out_dist, void* stream) {
+    VFE_REQUIRE(shard_idx && shard_dist && out_idx && out_dist && nshards > 0 && nq > 0, "NULL buffer or bad sizes");
+    ProfScope prof(VFE_K_MISC, (hipStream_t)stream);
+    /* input layout [nshards][nq][2] */
+    hipLaunchKernelGGL(k_merge, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, shard_idx, shard_dist, nshards,
+                       (size_t)1, (size_t)nq, nq, out_idx, out_dist);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
+extern "C" int vfe_dev_ratio_test(const int* idx, const int* dist, int nq, float ratio, uint8_t* good, void* stream) {
+    VFE_REQUIRE(idx && dist && good && nq > 0, "NULL buffer or nq <= 0");
+    hipLaunchKernelGGL(k_ratio, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, dist, nq, ratio, good);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}

@@ -1,0 +1,535 @@
+/* ORB keypoints + steered rBRIEF descriptors (cv::ORB::detectAndCompute semantics), batched.
+ *
+ * Per call: exact-bilinear pyramid (fixed-point INTER_LINEAR_EXACT weights computed on the GPU in
+ * IEEE double), FAST-9 + NMS per level (vfe_fast.hip), then per (frame, level):
+ *   k_orb_select  retainBest(2*quota) on the FAST score via a 256-bin histogram, Harris response
+ *                 of the survivors (7x7 block of integer Sobel products), retainBest(quota) on the
+ *                 response via a 3-pass radix select over order-preserving keys (ties kept),
+ *   k_orb_emit    stable compaction into the frame's output list at the level's base offset, so
+ *                 keypoints come out in (octave, y, x) order,
+ * then a 7x7 sigma-2 fixed-point Gaussian of every level through LDS tiles, and
+ *   k_orb_desc    one wavefront per keypoint: intensity-centroid angle (wave reduction), rotation
+ *                 by a deterministic double-precision sin/cos, 4 tap pairs per lane, and four
+ *                 ballots that are the descriptor's four 64-bit words.
+ */
+#include "vfe_common.h"
+#include "vfe_fast.h"
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+#define ORB_MAX_LEVELS 12
+#define ORB_EDGE 31
+#define ORB_PATCH 31
+#define ORB_HALF 15
+
+__constant__ signed char c_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+/* ---- level geometry (host; same expressions as OpenCV's ORB) ------------------------------ */
+static float orb_scale(int level, float scale_factor) { return (float)pow((double)scale_factor, (double)level); }
+
+extern "C" int vfe_orb_level_sizes(int width, int height, float scale_factor, int nlevels, int* wh, float* scales) {
+    VFE_REQUIRE(wh && nlevels >= 1 && nlevels <= ORB_MAX_LEVELS && scale_factor > 1.f, "bad ORB level parameters");
+    for (int l = 0; l < nlevels; l++) {
+        const float scale = orb_scale(l, scale_factor);
+        const float inv = 1.0f / scale;
+        wh[2 * l] = (int)lrintf(width * inv);
+        wh[2 * l + 1] = (int)lrintf(height * inv);
+        if (scales) scales[l] = scale;
+    }
+    return VFE_OK;
+}
+
+extern "C" int vfe_orb_quotas(int nfeatures, float scale_factor, int nlevels, int* quota) {
+    VFE_REQUIRE(quota && nlevels >= 1 && nlevels <= ORB_MAX_LEVELS && scale_factor > 1.f && nfeatures > 0, "bad ORB quota parameters");
+    const float factor = (float)(1.0 / scale_factor);
+    float nd = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) { quota[l] = (int)lrintf(nd); sum += quota[l]; nd *= factor; }
+    quota[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+    return VFE_OK;
+}
+
+/* ---- INTER_LINEAR_EXACT ------------------------------------------------------------------- */
+/* tab[v] = source offset << 9 | weight of the right/lower neighbour (0..256) */
+__global__ void k_orb_tables(int ssize, int dsize, u32* __restrict__ tab) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= dsize) return;
+    const double inv_scale = (double)dsize / (double)ssize;
+    const double scale = 1.0 / inv_scale;
+    const double f = scale * ((double)v + 0.5) - 0.5;
+    const int i = (int)floor(f);
+    u32 ofs = 0, w1 = 0;
+    if (i >= 0 && ssize > 1) {
+        if (i < ssize - 1) { ofs = (u32)i; w1 = (u32)(int)rint((f - (double)i) * 256.0); }
+        else ofs = (u32)(ssize - 1);
+    }
+    tab[v] = (ofs << 9) | w1;
+}
+
+__global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= dst.w) return;
+    const u32 ty = ytab[y], tx = xtab[x];
+    const int yo = ty >> 9, xo = tx >> 9;
+    const u32 wy1 = ty & 511, wy0 = 256 - wy1, wx1 = tx & 511, wx0 = 256 - wx1;
+    const uint8_t* r0 = src.frame(b) + (size_t)yo * src.pitch;
+    const uint8_t* r1 = src.frame(b) + (size_t)min(yo + 1, src.h - 1) * src.pitch;
+    const int x1 = min(xo + 1, src.w - 1);
+    const u32 h0 = r0[xo] * wx0 + r0[x1] * wx1;
+    const u32 h1 = r1[xo] * wx0 + r1[x1] * wx1;
+    const u32 v = h0 * wy0 + h1 * wy1;
+    dst.frame(b)[(size_t)y * dst.pitch + x] = (uint8_t)((v + (1u << 15)) >> 16);
+}
+
+/* ---- 7x7 Gaussian, sigma 2, 8.8 fixed point: taps 18 34 48 56 48 34 18 ------------------- */
+#define GB_TW 64
+#define GB_TH 16
+__global__ __launch_bounds__(256) void k_orb_blur(DImg src, DImg dst, int tiles_x, unsigned tiles_per_frame, unsigned total_work) {
+    __shared__ uint8_t s_in[GB_TH + 6][GB_TW + 8];
+    __shared__ unsigned short s_h[GB_TH + 6][GB_TW];
+    const int tid = threadIdx.x;
+    const int W = src.w, H = src.h;
+    for (unsigned work = blockIdx.x; work < total_work; work += gridDim.x) {
+        const int b = work / tiles_per_frame, tile = work - b * tiles_per_frame;
+        const int ox = (tile % tiles_x) * GB_TW, oy = (tile / tiles_x) * GB_TH;
+        const uint8_t* ip = src.frame(b);
+        for (int i = tid; i < (GB_TH + 6) * (GB_TW + 6); i += 256) {
+            const int r = i / (GB_TW + 6), c = i - r * (GB_TW + 6);
+            s_in[r][c] = ip[(size_t)reflect101(min(oy - 3 + r, H + 2), H) * src.pitch + reflect101(min(ox - 3 + c, W + 2), W)];
+        }
+        __syncthreads();
+        for (int i = tid; i < (GB_TH + 6) * GB_TW; i += 256) {
+            const int r = i / GB_TW, c = i - r * GB_TW;
+            const uint8_t* p = &s_in[r][c];
+            s_h[r][c] = (unsigned short)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+        }
+        __syncthreads();
+        for (int i = tid; i < GB_TH * GB_TW; i += 256) {
+            const int r = i / GB_TW, c = i - r * GB_TW;
+            const int px = ox + c, py = oy + r;
+            if (px < W && py < H) {
+                const u32 v = 18u * (s_h[r][c] + s_h[r + 6][c]) + 34u * (s_h[r + 1][c] + s_h[r + 5][c]) +
+                              48u * (s_h[r + 2][c] + s_h[r + 4][c]) + 56u * s_h[r + 3][c];
+                dst.frame(b)[(size_t)py * dst.pitch + px] = (uint8_t)((v + (1u << 15)) >> 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+/* ---- keypoint selection --------------------------------------------------------------------- */
+struct OrbLevels {
+    DImg raw[ORB_MAX_LEVELS];
+    DImg blur[ORB_MAX_LEVELS];
+    float scale[ORB_MAX_LEVELS];
+    int quota[ORB_MAX_LEVELS];
+    int cap[ORB_MAX_LEVELS];          /* FAST keypoint capacity of the level */
+    const int* kps[ORB_MAX_LEVELS];   /* [batch][cap][3] */
+    const int* cnt[ORB_MAX_LEVELS];   /* [batch] */
+    u32* key[ORB_MAX_LEVELS];         /* [batch][cap] order-preserving Harris keys, 0 = dropped */
+    uint8_t* keep[ORB_MAX_LEVELS];    /* [batch][cap] */
+    int nlevels;
+};
+
+__device__ static inline u32 float_key(float f) {
+    const u32 u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ static inline float key_float(u32 k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__device__ static inline float harris_response(const uint8_t* img, int pitch, int x0, int y0) {
+    int a = 0, b = 0, c = 0;
+    for (int i = 0; i < 7; i++) {
+        const uint8_t* r0 = img + (size_t)(y0 - 4 + i) * pitch + (x0 - 4);
+        const uint8_t* r1 = r0 + pitch;
+        const uint8_t* r2 = r1 + pitch;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int Ix = (r1[j + 2] - r1[j]) * 2 + (r0[j + 2] - r0[j]) + (r2[j + 2] - r2[j]);
+            const int Iy = (r2[j + 1] - r0[j + 1]) * 2 + (r2[j] - r0[j]) + (r2[j + 2] - r0[j + 2]);
+            a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+        }
+    }
+    const float scale = 1.f / ((float)((1 << 2) * 7) * 255.f);
+    const float scale4 = scale * scale * scale * scale;
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    const float s = fa + fb;
+    return ((fa * fb - fc * fc) - (0.04f * s) * s) * scale4;
+}
+
+__global__ __launch_bounds__(1024) void k_orb_select(OrbLevels L, int* __restrict__ lvl_count) {
+    __shared__ u32 s_hist[2048 + 1];
+    __shared__ u32 s_scan[2][1024];
+    __shared__ u32 s_val;
+    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cap = L.cap[l];
+    const int n = min(L.cnt[l][b], cap);
+    const int* kps = L.kps[l] + (size_t)b * cap * 3;
+    u32* key = L.key[l] + (size_t)b * cap;
+    uint8_t* keep = L.keep[l] + (size_t)b * cap;
+    const int quota = L.quota[l];
+    const DImg& I = L.raw[l];
+    const uint8_t* ip = I.frame(b);
+
+    /* retainBest(2*quota) on the FAST score: smallest kept score */
+    int smin = 0;
+    if (n > 2 * quota) {
+        if (2 * quota == 0) smin = 256;
+        else {
+            for (int i = tid; i < 256; i += 1024) s_hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) atomicAdd(&s_hist[kps[3 * i + 2] & 255], 1u);
+            __syncthreads();
+            if (tid == 0) {
+                u32 acc = 0; int s = 255;
+                for (; s > 0; s--) { acc += s_hist[s]; if (acc >= (u32)(2 * quota)) break; }
+                s_val = (u32)s;
+            }
+            __syncthreads();
+            smin = (int)s_val;
+            __syncthreads();
+        }
+    }
+    /* Harris response of the survivors */
+    u32 mine = 0;
+    for (int i = tid; i < n; i += 1024) {
+        u32 k = 0;
+        if (kps[3 * i + 2] >= smin) {
+            k = float_key(harris_response(ip, I.pitch, kps[3 * i], kps[3 * i + 1]));
+            mine++;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    /* number of survivors */
+    s_scan[0][tid] = mine;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) s_scan[0][tid] += s_scan[0][tid + o]; __syncthreads(); }
+    const u32 n1 = s_scan[0][0];
+    __syncthreads();
+    /* retainBest(quota) on the response: key of the quota-th largest, ties kept */
+    u32 T = 1; /* keep every survivor (keys are >= 1) */
+    if (n1 > (u32)quota) {
+        if (quota == 0) T = 0xFFFFFFFFu; /* nothing: real keys never reach this value... handled below */
+        else {
+            u32 prefix = 0, need = (u32)quota;
+            int hi = 32;
+            while (hi > 0) {
+                const int bits = hi >= 11 ? 11 : hi, sh = hi - bits;
+                for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
+                __syncthreads();
+                for (int i = tid; i < n; i += 1024) {
+                    const u32 k = key[i];
+                    if (k && (hi == 32 || (k >> hi) == prefix)) atomicAdd(&s_hist[(k >> sh) & ((1u << bits) - 1)], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    u32 acc = 0; int d = (1 << bits) - 1;
+                    for (; d > 0; d--) { if (acc + s_hist[d] >= need) break; acc += s_hist[d]; }
+                    s_val = (u32)d; s_hist[2048] = acc;
+                }
+                __syncthreads();
+                const u32 d = s_val;
+                need -= s_hist[2048];
+                prefix = (hi == 32 ? 0u : (prefix << bits)) | d;
+                hi = sh;
+                __syncthreads();
+            }
+            T = prefix;
+        }
+    }
+    u32 cnt = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const u32 k = key[i];
+        const bool kp = (k != 0) && (quota > 0) && (k >= T);
+        keep[i] = kp ? 1 : 0;
+        cnt += kp ? 1u : 0u;
+    }
+    s_scan[0][tid] = cnt;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) s_scan[0][tid] += s_scan[0][tid + o]; __syncthreads(); }
+    if (tid == 0) lvl_count[b * ORB_MAX_LEVELS + l] = (int)s_scan[0][0];
+}
+
+__global__ __launch_bounds__(1024) void k_orb_emit(OrbLevels L, const int* __restrict__ lvl_count,
+                                                   vfe_orb_kp* __restrict__ out, int out_cap, int* __restrict__ counts) {
+    __shared__ u32 s_scan[2][1024];
+    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cap = L.cap[l];
+    const int n = min(L.cnt[l][b], cap);
+    const int* kps = L.kps[l] + (size_t)b * cap * 3;
+    const u32* key = L.key[l] + (size_t)b * cap;
+    const uint8_t* keep = L.keep[l] + (size_t)b * cap;
+    int base = 0;
+    for (int k = 0; k < l; k++) base += lvl_count[b * ORB_MAX_LEVELS + k];
+    const float sf = L.scale[l];
+    /* stable compaction: thread t owns a contiguous slice */
+    const int per = (n + 1023) / 1024;
+    const int i0 = min(tid * per, n), i1 = min(i0 + per, n);
+    u32 mine = 0;
+    for (int i = i0; i < i1; i++) mine += keep[i];
+    int cur = 0;
+    s_scan[0][tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        u32 x = s_scan[cur][tid];
+        if (tid >= o) x += s_scan[cur][tid - o];
+        s_scan[cur ^ 1][tid] = x;
+        cur ^= 1;
+        __syncthreads();
+    }
+    int pos = base + (int)(s_scan[cur][tid] - mine);
+    for (int i = i0; i < i1; i++) {
+        if (!keep[i]) continue;
+        if (pos < out_cap) {
+            vfe_orb_kp kp;
+            kp.lx = kps[3 * i]; kp.ly = kps[3 * i + 1];
+            kp.x = (float)kp.lx * sf; kp.y = (float)kp.ly * sf;
+            kp.size = (float)ORB_PATCH * sf;
+            kp.angle = -1.f;
+            kp.response = key_float(key[i]);
+            kp.octave = l;
+            out[(size_t)b * out_cap + pos] = kp;
+        }
+        pos++;
+    }
+    if (l == L.nlevels - 1 && tid == 1023) counts[b] = min(base + (int)s_scan[cur][1023], out_cap);
+}
+
+/* ---- orientation + descriptor ---------------------------------------------------------------- */
+__device__ static inline float fast_atan2f_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI), p3 = -0.3258083974640975f * (float)(180 / M_PI),
+                p5 = 0.1555786518463281f * (float)(180 / M_PI), p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON); c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON); c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+/* same operation sequence as the CPU checker's deterministic sin/cos (double, one float rounding) */
+__device__ static inline void sincos_det(float xf, float* s_out, float* c_out) {
+    const double x = (double)xf;
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;
+    const double kd = rint(x * two_over_pi);
+    const int k = (int)kd;
+    double r = x - kd * pio2_hi;
+    r = r - kd * pio2_lo;
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double ps = S6;
+    ps = ps * z + S5; ps = ps * z + S4; ps = ps * z + S3; ps = ps * z + S2; ps = ps * z + S1;
+    const double sn = r + (r * z) * ps;
+    double pc = C6;
+    pc = pc * z + C5; pc = pc * z + C4; pc = pc * z + C3; pc = pc * z + C2; pc = pc * z + C1;
+    const double cs = (1.0 - 0.5 * z) + (z * z) * pc;
+    double s, c;
+    switch (k & 3) {
+        case 0: s = sn; c = cs; break;
+        case 1: s = cs; c = -sn; break;
+        case 2: s = -sn; c = -cs; break;
+        default: s = -cs; c = sn; break;
+    }
+    *s_out = (float)s; *c_out = (float)c;
+}
+
+__global__ __launch_bounds__(256) void k_orb_desc(OrbLevels L, vfe_orb_kp* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                  const int* __restrict__ counts, int out_cap, int batch) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    const unsigned total = (unsigned)batch * (unsigned)out_cap;
+    for (unsigned w = wave; w < total; w += nwaves) {
+        const int b = w / (unsigned)out_cap, i = w - (unsigned)b * (unsigned)out_cap;
+        if (i >= counts[b]) continue;
+        vfe_orb_kp* kp = kps + (size_t)b * out_cap + i;
+        const int l = kp->octave, px = kp->lx, py = kp->ly;
+        const DImg& I = L.raw[l];
+        const uint8_t* ip = I.frame(b);
+        /* intensity centroid over the circular patch: lane <-> column u, loop over rows v */
+        int m10 = 0, m01 = 0;
+        const int u = lane - ORB_HALF;
+        for (int v = -ORB_HALF; v <= ORB_HALF; v++) {
+            const int d = c_umax[v < 0 ? -v : v];
+            if (lane < ORB_PATCH && u >= -d && u <= d) {
+                const int val = ip[(size_t)(py + v) * I.pitch + px + u];
+                m10 += u * val; m01 += v * val;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+        const float angle = fast_atan2f_deg((float)m01, (float)m10);
+        /* steered BRIEF on the blurred level; the centre is recomputed from the scaled position */
+        const float sf = L.scale[l];
+        const float inv = 1.f / sf;
+        const int cx = __float2int_rn(kp->x * inv), cy = __float2int_rn(kp->y * inv);
+        float sa, ca;
+        sincos_det(angle * (float)(M_PI / 180.f), &sa, &ca);
+        const DImg& Bl = L.blur[l];
+        const uint8_t* bp = Bl.frame(b) + (size_t)cy * Bl.pitch + cx;
+        u64 words[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const signed char* pt = &c_pattern[(k * 64 + lane) * 4];
+            const float x0 = (float)pt[0] * ca - (float)pt[1] * sa, y0 = (float)pt[0] * sa + (float)pt[1] * ca;
+            const float x1 = (float)pt[2] * ca - (float)pt[3] * sa, y1 = (float)pt[2] * sa + (float)pt[3] * ca;
+            const int t0 = bp[(ptrdiff_t)__float2int_rn(y0) * Bl.pitch + __float2int_rn(x0)];
+            const int t1 = bp[(ptrdiff_t)__float2int_rn(y1) * Bl.pitch + __float2int_rn(x1)];
+            words[k] = __ballot(t0 < t1);
+        }
+        if (lane == 0) {
+            kp->angle = angle;
+            u64* d = reinterpret_cast<u64*>(desc + ((size_t)b * out_cap + i) * 32);
+            d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+        }
+    }
+}
+
+/* ---- host orchestration --------------------------------------------------------------------- */
+struct OrbWs {
+    int nlevels;
+    int w[ORB_MAX_LEVELS], h[ORB_MAX_LEVELS], pitch[ORB_MAX_LEVELS], cap[ORB_MAX_LEVELS];
+    size_t raw_off[ORB_MAX_LEVELS], blur_off[ORB_MAX_LEVELS], xtab_off[ORB_MAX_LEVELS], ytab_off[ORB_MAX_LEVELS];
+    size_t kps_off[ORB_MAX_LEVELS], cnt_off[ORB_MAX_LEVELS], key_off[ORB_MAX_LEVELS], keep_off[ORB_MAX_LEVELS];
+    size_t lvlcnt_off, fast_off, fast_bytes, total;
+};
+
+static int orb_layout(int width, int height, int batch, float scale_factor, int nlevels, OrbWs* L) {
+    int wh[2 * ORB_MAX_LEVELS];
+    int rc = vfe_orb_level_sizes(width, height, scale_factor, nlevels, wh, nullptr);
+    if (rc) return rc;
+    L->nlevels = nlevels;
+    size_t o = 0;
+    for (int l = 0; l < nlevels; l++) {
+        L->w[l] = wh[2 * l]; L->h[l] = wh[2 * l + 1];
+        if (L->w[l] < 1 || L->h[l] < 1) { vfe_set_error("ORB level %d is empty", l); return VFE_E_INVALID; }
+        L->pitch[l] = (int)align_up((size_t)L->w[l], 64);
+        L->cap[l] = (L->w[l] * L->h[l]) / 4 + 64;
+        const size_t img = align_up((size_t)batch * L->h[l] * L->pitch[l], 256);
+        L->raw_off[l] = o; if (l > 0) o += img;   /* level 0 is the caller's image */
+        L->blur_off[l] = o; o += img;
+        L->xtab_off[l] = o; o += align_up((size_t)L->w[l] * sizeof(u32), 256);
+        L->ytab_off[l] = o; o += align_up((size_t)L->h[l] * sizeof(u32), 256);
+        L->kps_off[l] = o; o += align_up((size_t)batch * L->cap[l] * 3 * sizeof(int), 256);
+        L->cnt_off[l] = o; o += align_up((size_t)batch * sizeof(int), 256);
+        L->key_off[l] = o; o += align_up((size_t)batch * L->cap[l] * sizeof(u32), 256);
+        L->keep_off[l] = o; o += align_up((size_t)batch * L->cap[l], 256);
+    }
+    L->lvlcnt_off = o; o += align_up((size_t)batch * ORB_MAX_LEVELS * sizeof(int), 256);
+    L->fast_bytes = 0;
+    for (int l = 0; l < nlevels; l++)
+        if (L->w[l] >= 7 && L->h[l] >= 7) {
+            size_t f = fast_layout(L->w[l], L->h[l], batch).total;
+            if (f > L->fast_bytes) L->fast_bytes = f;
+        }
+    L->fast_off = o; o += align_up(L->fast_bytes, 256);
+    L->total = o;
+    return VFE_OK;
+}
+
+extern "C" size_t vfe_orb_workspace(int width, int height, int batch, float scale_factor, int nlevels) {
+    if (width <= 0 || height <= 0 || batch <= 0 || nlevels < 1 || nlevels > ORB_MAX_LEVELS || !(scale_factor > 1.f)) return 0;
+    OrbWs L;
+    if (orb_layout(width, height, batch, scale_factor, nlevels, &L)) return 0;
+    return L.total;
+}
+
+extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float scale_factor, int nlevels,
+                                   int fast_threshold, vfe_orb_kp* kps, uint8_t* desc, int cap, int* counts,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = vfe_check_dimg(img, "img");
+    if (rc) return rc;
+    VFE_REQUIRE(nfeatures > 0 && nlevels >= 1 && nlevels <= ORB_MAX_LEVELS && scale_factor > 1.f, "bad ORB parameters");
+    VFE_REQUIRE(fast_threshold >= 1 && fast_threshold <= 254, "fast_threshold must be 1..254");
+    VFE_REQUIRE(kps && desc && counts && workspace && cap > 0, "NULL output or workspace");
+    VFE_REQUIRE((uintptr_t)workspace % 256 == 0 && (uintptr_t)desc % 8 == 0, "workspace/desc alignment");
+    VFE_REQUIRE(img->batch <= 65535, "batch too large");
+    OrbWs W;
+    if ((rc = orb_layout(img->width, img->height, img->batch, scale_factor, nlevels, &W))) return rc;
+    if (workspace_bytes < W.total) {
+        vfe_set_error("workspace too small: need %zu bytes, got %zu", W.total, workspace_bytes);
+        return VFE_E_NOMEM;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int batch = img->batch;
+    OrbLevels L;
+    memset(&L, 0, sizeof(L));
+    L.nlevels = nlevels;
+    float scales[ORB_MAX_LEVELS]; int wh[2 * ORB_MAX_LEVELS];
+    vfe_orb_level_sizes(img->width, img->height, scale_factor, nlevels, wh, scales);
+    vfe_orb_quotas(nfeatures, scale_factor, nlevels, L.quota);
+    for (int l = 0; l < nlevels; l++) {
+        DImg d; d.w = W.w[l]; d.h = W.h[l]; d.pitch = W.pitch[l]; d.batch = batch; d.fstride = (size_t)W.h[l] * W.pitch[l];
+        d.data = (uint8_t*)(ws + W.blur_off[l]);
+        L.blur[l] = d;
+        if (l == 0) L.raw[0] = to_dimg(img);
+        else { d.data = (uint8_t*)(ws + W.raw_off[l]); L.raw[l] = d; }
+        L.scale[l] = scales[l];
+        L.cap[l] = W.cap[l];
+        L.kps[l] = (const int*)(ws + W.kps_off[l]);
+        L.cnt[l] = (const int*)(ws + W.cnt_off[l]);
+        L.key[l] = (u32*)(ws + W.key_off[l]);
+        L.keep[l] = (uint8_t*)(ws + W.keep_off[l]);
+    }
+    int* lvl_count = (int*)(ws + W.lvlcnt_off);
+    /* pyramid */
+    for (int l = 1; l < nlevels; l++) {
+        ProfScope prof(VFE_K_ORB_RESIZE, st);
+        u32* xtab = (u32*)(ws + W.xtab_off[l]); u32* ytab = (u32*)(ws + W.ytab_off[l]);
+        hipLaunchKernelGGL(k_orb_tables, dim3(div_up(W.w[l], 256)), dim3(256), 0, st, W.w[l - 1], W.w[l], xtab);
+        hipLaunchKernelGGL(k_orb_tables, dim3(div_up(W.h[l], 256)), dim3(256), 0, st, W.h[l - 1], W.h[l], ytab);
+        hipLaunchKernelGGL(k_orb_resize, dim3(div_up(W.w[l], 256), W.h[l], batch), dim3(256), 0, st, L.raw[l - 1], L.raw[l], xtab, ytab);
+        VFE_LAUNCH_CHECK();
+    }
+    /* FAST per level (levels too small for the 31-pixel border yield nothing) */
+    for (int l = 0; l < nlevels; l++) {
+        if (W.w[l] > 2 * ORB_EDGE && W.h[l] > 2 * ORB_EDGE) {
+            if ((rc = fast_detect(L.raw[l], fast_threshold, ORB_EDGE, (int*)(ws + W.kps_off[l]), W.cap[l],
+                                  (int*)(ws + W.cnt_off[l]), ws + W.fast_off, st))) return rc;
+        } else {
+            VFE_HIP(hipMemsetAsync(ws + W.cnt_off[l], 0, (size_t)batch * sizeof(int), st));
+        }
+    }
+    {
+        ProfScope prof(VFE_K_ORB_SELECT, st);
+        hipLaunchKernelGGL(k_orb_select, dim3(nlevels, batch), dim3(1024), 0, st, L, lvl_count);
+        VFE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_orb_emit, dim3(nlevels, batch), dim3(1024), 0, st, L, lvl_count, kps, cap, counts);
+        VFE_LAUNCH_CHECK();
+    }
+    for (int l = 0; l < nlevels; l++) {
+        ProfScope prof(VFE_K_ORB_BLUR, st);
+        const int tiles_x = div_up(W.w[l], GB_TW), tiles_y = div_up(W.h[l], GB_TH);
+        const unsigned tpf = (unsigned)(tiles_x * tiles_y), total = tpf * (unsigned)batch;
+        hipLaunchKernelGGL(k_orb_blur, dim3(total < 2048u ? total : 2048u), dim3(256), 0, st, L.raw[l], L.blur[l], tiles_x, tpf, total);
+        VFE_LAUNCH_CHECK();
+    }
+    {
+        ProfScope prof(VFE_K_ORB_DESC, st);
+        const unsigned waves = (unsigned)batch * (unsigned)cap;
+        const unsigned blocks = (waves + 3) / 4;
+        hipLaunchKernelGGL(k_orb_desc, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, L, kps, desc, counts, cap, batch);
+        VFE_LAUNCH_CHECK();
+    }
+    return VFE_OK;
+}

@@ -3,17 +3,7 @@
 #include "vfe_common.h"
 #define TODO(name) do { vfe_set_error(name ": not implemented yet"); return VFE_E_INVALID; } while (0)
 extern "C" {
-int vfe_dev_bgr2gray(const vfe_dimg*, const vfe_dimg*, void*) { TODO("vfe_dev_bgr2gray"); }
-size_t vfe_fast_workspace(int, int, int) { return 0; }
-int vfe_dev_fast9(const vfe_dimg*, int, int*, int, int*, void*, size_t, void*) { TODO("vfe_dev_fast9"); }
 int vfe_dev_fast_grid(const vfe_dimg*, int, int, int, int, int, const float*, const int*, int, float*, int*, int, int*, void*, size_t, void*) { TODO("vfe_dev_fast_grid"); }
-size_t vfe_orb_workspace(int, int, int, int, int) { return 0; }
-int vfe_orb_level_sizes(int, int, float, int, int*, float*) { TODO("vfe_orb_level_sizes"); }
-int vfe_orb_quotas(int, float, int, int*) { TODO("vfe_orb_quotas"); }
-int vfe_dev_orb_extract(const vfe_dimg*, int, float, int, int, vfe_orb_kp*, uint8_t*, int, int*, void*, size_t, void*) { TODO("vfe_dev_orb_extract"); }
-int vfe_dev_match_knn2(const uint8_t*, int, const uint8_t*, long long, int, int*, int*, void*) { TODO("vfe_dev_match_knn2"); }
-int vfe_dev_merge_knn2(const int*, const int*, int, int, int*, int*, void*) { TODO("vfe_dev_merge_knn2"); }
-int vfe_dev_ratio_test(const int*, const int*, int, float, uint8_t*, void*) { TODO("vfe_dev_ratio_test"); }
 int vfe_create(const vfe_config*, vfe_ctx**) { TODO("vfe_create"); }
 void vfe_destroy(vfe_ctx*) {}
 int vfe_reset(vfe_ctx*) { TODO("vfe_reset"); }
