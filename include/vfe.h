@@ -183,8 +183,13 @@ int vfe_dev_fast9(const vfe_dimg* img, int threshold, int* kps, int cap, int* co
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* FAST per grid cell + best-per-cell + occupancy min distance (config/openvins.yaml:29-37:
- * fast_threshold, grid_x, grid_y, min_px_dist, num_pts).  pts_xy [batch][cap][2],
+ * fast_threshold, grid_x, grid_y, min_px_dist, num_pts; struct fields
+ * include/slam/adapters/openvins_adapter.hpp:29-32).  FAST runs on each of the grid_x*grid_y
+ * cells as an image of its own; the (num_features - n_seeds)/(cells) + 1 best of each cell by
+ * score (ties: raster order) are offered cell by cell to an occupancy grid of min_px_dist pixels
+ * that the seeds (existing tracks) have marked first.  pts_xy [batch][cap][2],
  * scores [batch][cap], counts [batch]; cap >= num_features + grid_x*grid_y. */
+size_t vfe_fast_grid_workspace(int width, int height, int batch, int grid_x, int grid_y, int min_px_dist);
 int vfe_dev_fast_grid(const vfe_dimg* img, int threshold, int grid_x, int grid_y, int num_features,
                       int min_px_dist, const float* seeds_xy, const int* n_seeds, int seed_cap,
                       float* pts_xy, int* scores, int cap, int* counts,

@@ -1,0 +1,122 @@
+"""GPU parity for the host-pointer context API (what the framework adapters call) and the
+grid-bucketed FAST detector, against the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+from vi_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(cuda):
+    c = capi.Context(1920, 1080, max_features=2000, pyramid_levels=4, win_size=21, orb_levels=8)
+    yield c
+    c.close()
+
+
+def test_ctx_detect_matches_reference_calls(ctx):
+    """The two goodFeaturesToTrack calls of the reference, with its defaults:
+    openvins_adapter.cpp:79-80 (N=200, q=0.01, d=10), basalt_adapter.cpp:50-53 (N=200, q=0.007, d=10)."""
+    im = synth.scene(synth.BASE_SEED + 20, 752, 480, 0)
+    for (n, q, d) in [(200, 0.01, 10), (200, 0.7 * 0.01, 10), (150, 0.01, 30)]:
+        got = ctx.detect_shi_tomasi(im, n, q, d)
+        ref, _ = ora.good_features(im, n, q, d)
+        assert np.array_equal(got, ref)
+
+
+def test_ctx_detect_bgr_input(ctx):
+    rng = np.random.default_rng(3)
+    gray = synth.scene(synth.BASE_SEED + 21, 640, 480, 0)
+    bgr = np.stack([gray, np.roll(gray, 3, axis=1), rng.integers(0, 255, gray.shape, dtype=np.uint8)], axis=2)
+    got = ctx.detect_shi_tomasi(bgr, 200, 0.01, 10)
+    ref, _ = ora.good_features(ora.bgr2gray(bgr), 200, 0.01, 10)
+    assert np.array_equal(got, ref)
+
+
+def test_ctx_constant_image_yields_nothing(ctx):
+    """The reference's own unit-test frame: 640x480 constant 128 (tests/test_openvins_adapter.cpp:63)."""
+    im = np.full((480, 640), 128, np.uint8)
+    assert len(ctx.detect_shi_tomasi(im, 200, 0.01, 10)) == 0
+    k, d = ctx.orb_extract(im, 1200)
+    assert len(k) == 0
+
+
+def test_ctx_klt(ctx):
+    w, h = 752, 480
+    a, b = synth.scene(synth.BASE_SEED + 22, w, h, 0), synth.scene(synth.BASE_SEED + 22, w, h, 1)
+    pts, _ = ora.good_features(a, 150, 0.01, 30)
+    out, st, err = ctx.klt_track(a, b, pts, max_level=2)
+    ro, rs, re = ora.klt_track(a, b, pts, 21, 2)
+    assert np.array_equal(st, rs)
+    assert np.abs(out - ro).max() <= 1e-3
+    assert np.array_equal(out.view(np.uint32), ro.view(np.uint32))
+    assert np.array_equal(err.view(np.uint32), re.view(np.uint32))
+
+
+def test_ctx_orb_and_match(ctx):
+    w, h = 752, 480
+    a, b = synth.scene(synth.BASE_SEED + 23, w, h, 0), synth.scene(synth.BASE_SEED + 23, w, h, 1)
+    ka, da = ctx.orb_extract(a, 1200)   # ORBSLAM3Config::nFeatures default (orbslam3_adapter.hpp:69)
+    kb, db = ctx.orb_extract(b, 1200)
+    rka, rda = ora.orb_extract(a, 1200)
+    assert len(ka) == len(rka) and np.array_equal(da, rda)
+    assert np.array_equal(ka["lx"], rka["lx"]) and np.array_equal(ka["angle"].view(np.uint32), rka["angle"].view(np.uint32))
+    idx, dist, good = ctx.match_knn2(da, db, 0.7)
+    ridx, rdist = ora.match_knn2(da, db)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert np.array_equal(good, ora.ratio_test(ridx, rdist, 0.7))
+
+
+def test_ctx_process_frame_stream(ctx):
+    """vins_mono.yaml shape (752x480, max_cnt 150, min_dist 30): five frames of one stream."""
+    w, h, n, d = 752, 480, 150, 30
+    ctx.reset()
+    seq = [synth.scene(synth.BASE_SEED + 24, w, h, t) for t in range(5)]
+    ref, _ = ora.good_features(seq[0], n, 0.01, d)
+    tr, det, tot = ctx.process_frame(seq[0], 0, n, 0.01, d)
+    assert (tr, det, tot) == (0, len(ref), len(ref))
+    assert np.array_equal(ctx.points(), ref)
+    for t in range(1, 5):
+        tr, det, tot = ctx.process_frame(seq[t], t * 50_000_000, n, 0.01, d)
+        nxt, st, _ = ora.klt_track(seq[t - 1], seq[t], ref, 21, 3)
+        r = np.rint(nxt)
+        keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < w - 1) & (r[:, 1] >= 1) & (r[:, 1] < h - 1)
+        tracked = nxt[keep]
+        ref = tracked
+        if n - len(tracked) > 0:
+            new, _ = ora.good_features(seq[t], n - len(tracked), 0.01, d, seeds=tracked)
+            ref = np.concatenate([tracked, new]) if len(new) else tracked
+        assert (tr, tot) == (len(tracked), len(ref))
+        assert np.array_equal(ctx.points().view(np.uint32), ref.view(np.uint32))
+    ctx.reset()
+    assert len(ctx.points()) == 0
+
+
+def test_ctx_errors_do_not_throw(ctx):
+    L = capi.lib()
+    with pytest.raises(capi.VfeError):
+        ctx.detect_shi_tomasi(np.zeros((2000, 3000), np.uint8), 10, 0.01, 10)   # larger than the context
+    with pytest.raises(capi.VfeError):
+        ctx.detect_shi_tomasi(np.zeros((480, 640, 2), np.uint8), 10, 0.01, 10)  # 2 channels
+    assert b"" != L.vfe_last_error()
+
+
+@pytest.mark.parametrize("w,h,gx,gy,n,d", [(752, 480, 5, 5, 200, 10), (640, 480, 8, 5, 400, 15), (1920, 1080, 5, 5, 1000, 20)])
+def test_fast_grid_bit_exact(cuda, w, h, gx, gy, n, d):
+    import torch
+    imgs = [synth.scene(synth.BASE_SEED + 25, w, h, 0), synth.noise(31, w, h)]
+    t = capi.alloc_image(2, h, w, cuda)
+    t.copy_(torch.from_numpy(np.stack(imgs)).to(cuda))
+    seeds0, _ = ora.good_features(imgs[0], 40, 0.01, d)
+    sd = torch.zeros((2, 64, 2), dtype=torch.float32, device=cuda)
+    sd[0, :len(seeds0)] = torch.from_numpy(seeds0).to(cuda)
+    ns = torch.tensor([len(seeds0), 0], dtype=torch.int32, device=cuda)
+    pts, sc, cnt = capi.fast_grid(t, 20, gx, gy, n, d, sd, ns)
+    pts, sc, cnt = pts.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+    for i, im in enumerate(imgs):
+        rxy, rsc = ora.fast_grid(im, 20, gx, gy, n, d, seeds0 if i == 0 else None)
+        assert cnt[i] == len(rxy), f"frame {i}: {cnt[i]} vs {len(rxy)}"
+        assert np.array_equal(pts[i, :cnt[i]], rxy) and np.array_equal(sc[i, :cnt[i]], rsc)
+        assert cnt[i] > 0

@@ -74,6 +74,7 @@ SIGNATURES = {
     "vfe_prof_kernel_name": (C.c_char_p, [C.c_int]),
     "vfe_fast_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "vfe_dev_fast9": (C.c_int, [_DI, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, _P]),
+    "vfe_fast_grid_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vfe_dev_fast_grid": (C.c_int, [_DI, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P,
                                     C.c_int, _P, _P, C.c_size_t, _P]),
     "vfe_orb_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
@@ -365,3 +366,104 @@ def ratio_test(idx, dist, ratio=0.7):
     good = torch.empty(nq, dtype=torch.uint8, device=idx.device)
     check(lib().vfe_dev_ratio_test(_ptr(idx), _ptr(dist), nq, ratio, _ptr(good), _stream()))
     return good
+
+
+def fast_grid(img, threshold, grid_x, grid_y, num_features, min_px_dist, seeds=None, n_seeds=None):
+    """(pts [B, cap, 2] float32, scores [B, cap] int32, counts [B])."""
+    import torch
+    b, h, w = img.shape
+    cap = num_features + grid_x * grid_y + 16
+    nbytes = lib().vfe_fast_grid_workspace(w, h, b, grid_x, grid_y, min_px_dist)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=img.device)
+    pts = torch.zeros((b, cap, 2), dtype=torch.float32, device=img.device)
+    sc = torch.zeros((b, cap), dtype=torch.int32, device=img.device)
+    counts = torch.zeros(b, dtype=torch.int32, device=img.device)
+    check(lib().vfe_dev_fast_grid(C.byref(dimg(img)), threshold, grid_x, grid_y, num_features, min_px_dist,
+                                  _ptr(seeds), _ptr(n_seeds), seeds.shape[1] if seeds is not None else 0,
+                                  _ptr(pts), _ptr(sc), cap, _ptr(counts), _ptr(ws), nbytes, _stream()))
+    return pts, sc, counts
+
+
+class Context:
+    """vfe_ctx: the host-pointer API the framework adapters use (numpy in, numpy out)."""
+
+    def __init__(self, max_width, max_height, max_features=1000, pyramid_levels=4, win_size=21, orb_levels=8, device=0):
+        self._h = C.c_void_p()
+        cfg = Config(device, max_width, max_height, max_features, pyramid_levels, win_size, orb_levels)
+        check(lib().vfe_create(C.byref(cfg), C.byref(self._h)))
+        self.max_features = max_features
+
+    def close(self):
+        if self._h:
+            lib().vfe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _img(a):
+        a = np.ascontiguousarray(a, np.uint8)
+        ch = 1 if a.ndim == 2 else a.shape[2]
+        return a, a.ctypes.data, a.shape[0], a.shape[1], a.strides[0], ch
+
+    def reset(self):
+        check(lib().vfe_reset(self._h))
+
+    def detect_shi_tomasi(self, img, max_corners, quality, min_distance):
+        a, p, rows, cols, step, ch = self._img(img)
+        out = np.zeros((max_corners, 2), np.float32)
+        n = C.c_int(0)
+        check(lib().vfe_detect_shi_tomasi(self._h, p, rows, cols, step, ch, max_corners, quality, min_distance,
+                                          out.ctypes.data, C.byref(n)))
+        return out[:n.value].copy()
+
+    def klt_track(self, prev, nxt, pts, max_level=3, max_iter=30, eps=0.01, min_eig_thr=1e-4):
+        a, pa, rows, cols, step, _ = self._img(prev)
+        b, pb, _, _, step_b, _ = self._img(nxt)
+        assert step == step_b
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        n = len(pts)
+        out = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        check(lib().vfe_klt_track(self._h, pa, pb, rows, cols, step, pts.ctypes.data, n, out.ctypes.data,
+                                  st.ctypes.data, err.ctypes.data, max_level, max_iter, eps, min_eig_thr))
+        return out, st, err
+
+    def orb_extract(self, img, nfeatures, scale_factor=1.2, nlevels=8, fast_threshold=20):
+        a, p, rows, cols, step, ch = self._img(img)
+        cap = 2 * nfeatures + 256
+        kps = np.zeros(cap, ORB_KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        check(lib().vfe_orb_extract(self._h, p, rows, cols, step, ch, nfeatures, scale_factor, nlevels, fast_threshold,
+                                    kps.ctypes.data, desc.ctypes.data, cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def match_knn2(self, query, train, ratio=0.7):
+        q = np.ascontiguousarray(query, np.uint8)
+        t = np.ascontiguousarray(train, np.uint8)
+        nq, nt = len(q), len(t)
+        idx = np.zeros((nq, 2), np.int32)
+        dist = np.zeros((nq, 2), np.int32)
+        good = np.zeros(nq, np.uint8)
+        check(lib().vfe_match_knn2(self._h, q.ctypes.data, nq, t.ctypes.data if nt else None, nt, ratio,
+                                   idx.ctypes.data, dist.ctypes.data, good.ctypes.data))
+        return idx, dist, good
+
+    def process_frame(self, img, timestamp_ns, max_corners, quality, min_distance):
+        a, p, rows, cols, step, ch = self._img(img)
+        st = FrameStats()
+        check(lib().vfe_process_frame(self._h, p, rows, cols, step, ch, timestamp_ns, max_corners, quality,
+                                      min_distance, C.byref(st)))
+        return st.n_tracked, st.n_detected, st.n_total
+
+    def points(self):
+        out = np.zeros((self.max_features, 2), np.float32)
+        n = C.c_int(0)
+        check(lib().vfe_get_points(self._h, out.ctypes.data, self.max_features, C.byref(n)))
+        return out[:n.value].copy()

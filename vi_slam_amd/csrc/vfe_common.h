@@ -52,13 +52,23 @@ struct DImg {
     uint8_t* data;
     int w, h, pitch, batch;
     size_t fstride;
-    __host__ __device__ const uint8_t* frame(int b) const { return data + (size_t)b * fstride; }
-    __host__ __device__ uint8_t* frame(int b) { return data + (size_t)b * fstride; }
+    /* optional second level: each frame is cut into sub_n equal windows (sub_gx per row,
+     * sub_dx bytes apart horizontally, sub_dy bytes apart vertically) and `batch` counts
+     * windows; sub_n = 1 means whole frames */
+    int sub_n, sub_gx, sub_dx;
+    size_t sub_dy;
+    __host__ __device__ size_t offset(int b) const {
+        if (sub_n == 1) return (size_t)b * fstride;
+        const int f = b / sub_n, c = b - f * sub_n, cy = c / sub_gx, cx = c - cy * sub_gx;
+        return (size_t)f * fstride + (size_t)cy * sub_dy + (size_t)cx * sub_dx;
+    }
+    __host__ __device__ const uint8_t* frame(int b) const { return data + offset(b); }
+    __host__ __device__ uint8_t* frame(int b) { return data + offset(b); }
 };
 
 static inline DImg to_dimg(const vfe_dimg* v) {
     DImg d; d.data = v->data; d.w = v->width; d.h = v->height; d.pitch = v->pitch; d.batch = v->batch;
-    d.fstride = v->frame_stride; return d;
+    d.fstride = v->frame_stride; d.sub_n = 1; d.sub_gx = 1; d.sub_dx = 0; d.sub_dy = 0; return d;
 }
 
 static inline int vfe_check_dimg(const vfe_dimg* v, const char* name) {

@@ -1,0 +1,303 @@
+/* Host-pointer context API: what a framework adapter calls from processImage
+ * (reference boundary: include/slam/i_slam_framework.hpp:63; adapters' feedImage at
+ * src/slam/adapters/openvins_adapter.cpp:59-86, basalt_adapter.cpp:32-64,
+ * orbslam3_adapter.cpp:51-116).  Owns one stream, the device images of the previous and the
+ * current frame with their LK pyramids, the track list and all workspaces; every call copies
+ * the caller's host image in, enqueues the batched device entry points with batch = 1 and
+ * blocks until the outputs are back in the caller's buffers. */
+#include "vfe_common.h"
+#include <new>
+#include <string.h>
+
+#define CTX_MAX_LK_LEVELS 8
+
+extern "C" size_t vfe_match_workspace(int nq, long long nt);
+
+struct vfe_ctx {
+    vfe_config cfg;
+    hipStream_t stream;
+    int pitch[CTX_MAX_LK_LEVELS], lw[CTX_MAX_LK_LEVELS], lh[CTX_MAX_LK_LEVELS];
+    uint8_t* pyr[2][CTX_MAX_LK_LEVELS]; /* [slot][level]; level 0 = the uploaded gray frame */
+    uint8_t* bgr;                       /* staging for 3-channel input */
+    float *pts, *next_pts, *corners, *err;
+    uint8_t* status;
+    int *n_pts, *n_tracked, *counts;
+    void* ws; size_t ws_bytes;
+    vfe_orb_kp* orb_kps; uint8_t* orb_desc; int orb_cap;
+    void* mws; size_t mws_bytes;        /* growable: match descriptors + workspace */
+    int cur, have_prev, w, h;           /* stream state */
+};
+
+static int ctx_enter(vfe_ctx* c) {
+    VFE_REQUIRE(c, "ctx is NULL");
+    VFE_HIP(hipSetDevice(c->cfg.device));
+    return VFE_OK;
+}
+
+static vfe_dimg ctx_level(vfe_ctx* c, int slot, int level, int w, int h) {
+    vfe_dimg d; d.data = c->pyr[slot][level]; d.width = w; d.height = h; d.pitch = c->pitch[level]; d.batch = 1;
+    d.frame_stride = (size_t)d.pitch * h;
+    return d;
+}
+
+/* fill levels[] for a w x h frame in `slot`; returns number of levels (<= cfg.pyramid_levels) */
+static int ctx_levels(vfe_ctx* c, int slot, int w, int h, int max_level, vfe_dimg* levels) {
+    const int ml = vfe_lk_max_level(w, h, c->cfg.win_size, max_level);
+    int lw = w, lh = h;
+    for (int l = 0; l <= ml; l++) {
+        levels[l] = ctx_level(c, slot, l, lw, lh);
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+    }
+    return ml + 1;
+}
+
+static int ctx_upload(vfe_ctx* c, int slot, const uint8_t* data, int rows, int cols, size_t step, int channels) {
+    VFE_REQUIRE(data && rows > 0 && cols > 0, "empty image");
+    VFE_REQUIRE(channels == 1 || channels == 3, "channels must be 1 (gray) or 3 (BGR)");
+    VFE_REQUIRE(cols <= c->cfg.max_width && rows <= c->cfg.max_height, "image larger than the context was created for");
+    VFE_REQUIRE(step >= (size_t)cols * channels, "step smaller than a row");
+    if (channels == 1) {
+        VFE_HIP(hipMemcpy2DAsync(c->pyr[slot][0], c->pitch[0], data, step, cols, rows, hipMemcpyHostToDevice, c->stream));
+    } else {
+        const size_t bp = (size_t)c->cfg.max_width * 3;
+        VFE_HIP(hipMemcpy2DAsync(c->bgr, bp, data, step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, c->stream));
+        vfe_dimg s; s.data = c->bgr; s.width = cols; s.height = rows; s.pitch = (int)bp; s.batch = 1; s.frame_stride = bp * rows;
+        vfe_dimg g = ctx_level(c, slot, 0, cols, rows);
+        int rc = vfe_dev_bgr2gray(&s, &g, c->stream);
+        if (rc) return rc;
+    }
+    return VFE_OK;
+}
+
+extern "C" void vfe_destroy(vfe_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int s = 0; s < 2; s++)
+        for (int l = 0; l < CTX_MAX_LK_LEVELS; l++) (void)hipFree(c->pyr[s][l]);
+    void* bufs[] = {c->bgr, c->pts, c->next_pts, c->corners, c->err, c->status, c->n_pts, c->n_tracked, c->counts,
+                    c->ws, c->orb_kps, c->orb_desc, c->mws};
+    for (void* p : bufs) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
+    VFE_REQUIRE(cfg && out, "NULL argument");
+    *out = nullptr;
+    VFE_REQUIRE(cfg->max_width >= 8 && cfg->max_height >= 8 && cfg->max_width < 32768 && cfg->max_height < 32768, "bad max image size");
+    VFE_REQUIRE(cfg->max_features > 0 && cfg->max_features <= (1 << 20), "bad max_features");
+    VFE_REQUIRE(cfg->pyramid_levels >= 1 && cfg->pyramid_levels <= CTX_MAX_LK_LEVELS, "pyramid_levels must be 1..8");
+    VFE_REQUIRE(cfg->win_size >= 3 && cfg->win_size <= 41 && (cfg->win_size & 1), "win_size must be odd, 3..41");
+    VFE_REQUIRE(cfg->orb_levels >= 0 && cfg->orb_levels <= 12, "orb_levels must be 0..12");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        vfe_set_error("no HIP device is visible: the front-end has no CPU fallback");
+        return VFE_E_NODEVICE;
+    }
+    VFE_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "device ordinal out of range");
+    VFE_HIP(hipSetDevice(cfg->device));
+    vfe_ctx* c = new (std::nothrow) vfe_ctx;
+    if (!c) { vfe_set_error("out of host memory"); return VFE_E_NOMEM; }
+    memset(c, 0, sizeof(*c));
+    c->cfg = *cfg;
+#define CTX_TRY(call)                                                           \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            vfe_set_error("%s failed: %s", #call, hipGetErrorString(e_));       \
+            vfe_destroy(c);                                                     \
+            return e_ == hipErrorOutOfMemory ? VFE_E_NOMEM : VFE_E_HIP;         \
+        }                                                                       \
+    } while (0)
+    CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    int lw = cfg->max_width, lh = cfg->max_height;
+    for (int l = 0; l < cfg->pyramid_levels; l++) {
+        c->lw[l] = lw; c->lh[l] = lh; c->pitch[l] = (int)align_up((size_t)lw, 256);
+        for (int s = 0; s < 2; s++) CTX_TRY(hipMalloc((void**)&c->pyr[s][l], (size_t)c->pitch[l] * lh));
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+    }
+    const size_t N = (size_t)cfg->max_features;
+    CTX_TRY(hipMalloc((void**)&c->bgr, (size_t)cfg->max_width * 3 * cfg->max_height));
+    CTX_TRY(hipMalloc((void**)&c->pts, N * 2 * sizeof(float)));
+    CTX_TRY(hipMalloc((void**)&c->next_pts, N * 2 * sizeof(float)));
+    CTX_TRY(hipMalloc((void**)&c->corners, N * 2 * sizeof(float)));
+    CTX_TRY(hipMalloc((void**)&c->err, N * sizeof(float)));
+    CTX_TRY(hipMalloc((void**)&c->status, N));
+    CTX_TRY(hipMalloc((void**)&c->n_pts, 256));
+    CTX_TRY(hipMalloc((void**)&c->n_tracked, 256));
+    CTX_TRY(hipMalloc((void**)&c->counts, 256));
+    CTX_TRY(hipMemsetAsync(c->n_pts, 0, 256, c->stream));
+    size_t ws = vfe_frontend_workspace(cfg->max_width, cfg->max_height, 1, cfg->max_features);
+    if (cfg->orb_levels > 0) {
+        const size_t o = vfe_orb_workspace(cfg->max_width, cfg->max_height, 1, 1.2f, cfg->orb_levels);
+        if (o > ws) ws = o;
+        c->orb_cap = 2 * cfg->max_features + 256;
+        CTX_TRY(hipMalloc((void**)&c->orb_kps, (size_t)c->orb_cap * sizeof(vfe_orb_kp)));
+        CTX_TRY(hipMalloc((void**)&c->orb_desc, (size_t)c->orb_cap * 32));
+    }
+    c->ws_bytes = ws;
+    CTX_TRY(hipMalloc(&c->ws, ws));
+    CTX_TRY(hipStreamSynchronize(c->stream));
+#undef CTX_TRY
+    *out = c;
+    return VFE_OK;
+}
+
+extern "C" int vfe_reset(vfe_ctx* c) {
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    c->have_prev = 0; c->cur = 0; c->w = c->h = 0;
+    VFE_HIP(hipMemsetAsync(c->n_pts, 0, sizeof(int), c->stream));
+    VFE_HIP(hipStreamSynchronize(c->stream));
+    return VFE_OK;
+}
+
+extern "C" int vfe_detect_shi_tomasi(vfe_ctx* c, const uint8_t* data, int rows, int cols, size_t step, int channels,
+                                     int max_corners, double quality, double min_distance,
+                                     float* corners_xy, int* n_out) {
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    VFE_REQUIRE(corners_xy && n_out, "NULL output");
+    VFE_REQUIRE(max_corners > 0 && max_corners <= c->cfg.max_features, "max_corners exceeds the context's max_features");
+    const int slot = c->cur ^ 1; /* scratch slot: does not disturb the stream's previous frame */
+    if ((rc = ctx_upload(c, slot, data, rows, cols, step, channels))) return rc;
+    vfe_dimg img = ctx_level(c, slot, 0, cols, rows);
+    if ((rc = vfe_dev_good_features(&img, max_corners, quality, min_distance, nullptr, nullptr, 0, c->corners, nullptr,
+                                    c->counts, c->ws, c->ws_bytes, c->stream))) return rc;
+    int n = 0;
+    VFE_HIP(hipMemcpyAsync(&n, c->counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipStreamSynchronize(c->stream));
+    if (n > 0) VFE_HIP(hipMemcpy(corners_xy, c->corners, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    *n_out = n;
+    return VFE_OK;
+}
+
+extern "C" int vfe_klt_track(vfe_ctx* c, const uint8_t* prev, const uint8_t* next, int rows, int cols, size_t step,
+                             const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err,
+                             int max_level, int max_iter, double eps, double min_eig_thr) {
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    VFE_REQUIRE(prev_pts && next_pts && status, "NULL point buffers");
+    VFE_REQUIRE(n >= 0 && n <= c->cfg.max_features, "n exceeds the context's max_features");
+    VFE_REQUIRE(max_level >= 0 && max_level < c->cfg.pyramid_levels, "max_level exceeds the context's pyramid_levels");
+    if (n == 0) return VFE_OK;
+    /* uses both slots: the stream's previous frame is forgotten */
+    c->have_prev = 0;
+    if ((rc = ctx_upload(c, 0, prev, rows, cols, step, 1)) || (rc = ctx_upload(c, 1, next, rows, cols, step, 1))) return rc;
+    vfe_dimg pl[CTX_MAX_LK_LEVELS], nl[CTX_MAX_LK_LEVELS];
+    const int nlev = ctx_levels(c, 0, cols, rows, max_level, pl);
+    ctx_levels(c, 1, cols, rows, max_level, nl);
+    if ((rc = vfe_dev_build_pyramid(pl, nlev, c->stream)) || (rc = vfe_dev_build_pyramid(nl, nlev, c->stream))) return rc;
+    VFE_HIP(hipMemcpyAsync(c->pts, prev_pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    VFE_HIP(hipMemcpyAsync(c->n_tracked, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if ((rc = vfe_dev_klt_track(pl, nl, nlev, c->pts, c->n_tracked, c->cfg.max_features, c->next_pts, c->status, c->err,
+                                c->cfg.win_size, max_iter, eps, min_eig_thr, 0, c->stream))) return rc;
+    VFE_HIP(hipMemcpyAsync(next_pts, c->next_pts, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(status, c->status, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (err) VFE_HIP(hipMemcpyAsync(err, c->err, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemsetAsync(c->n_pts, 0, sizeof(int), c->stream));
+    VFE_HIP(hipStreamSynchronize(c->stream));
+    return VFE_OK;
+}
+
+extern "C" int vfe_orb_extract(vfe_ctx* c, const uint8_t* data, int rows, int cols, size_t step, int channels,
+                               int nfeatures, float scale_factor, int nlevels, int fast_threshold,
+                               vfe_orb_kp* kps, uint8_t* desc, int cap, int* n_out) {
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    VFE_REQUIRE(kps && desc && n_out && cap > 0, "NULL output");
+    VFE_REQUIRE(c->cfg.orb_levels > 0, "context was created without ORB (orb_levels = 0)");
+    VFE_REQUIRE(nlevels >= 1 && nlevels <= c->cfg.orb_levels, "nlevels exceeds the context's orb_levels");
+    VFE_REQUIRE(scale_factor >= 1.2f, "contexts size their ORB workspace for scale_factor >= 1.2");
+    const int slot = c->cur ^ 1;
+    if ((rc = ctx_upload(c, slot, data, rows, cols, step, channels))) return rc;
+    vfe_dimg img = ctx_level(c, slot, 0, cols, rows);
+    const int dcap = cap < c->orb_cap ? cap : c->orb_cap;
+    if ((rc = vfe_dev_orb_extract(&img, nfeatures, scale_factor, nlevels, fast_threshold, c->orb_kps, c->orb_desc, dcap,
+                                  c->counts, c->ws, c->ws_bytes, c->stream))) return rc;
+    int n = 0;
+    VFE_HIP(hipMemcpyAsync(&n, c->counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipStreamSynchronize(c->stream));
+    if (n > 0) {
+        VFE_HIP(hipMemcpy(kps, c->orb_kps, (size_t)n * sizeof(vfe_orb_kp), hipMemcpyDeviceToHost));
+        VFE_HIP(hipMemcpy(desc, c->orb_desc, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    *n_out = n;
+    return VFE_OK;
+}
+
+extern "C" int vfe_match_knn2(vfe_ctx* c, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                              float ratio, int* idx, int* dist, uint8_t* good) {
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    VFE_REQUIRE(query && idx && dist && nq > 0 && nt >= 0 && (nt == 0 || train), "NULL buffer or bad sizes");
+    const size_t qb = align_up((size_t)nq * 32, 256), tb = align_up((size_t)nt * 32 + 32, 256);
+    const size_t ob = align_up((size_t)nq * 2 * sizeof(int), 256), gb = align_up((size_t)nq, 256);
+    const size_t wb = vfe_match_workspace(nq, nt);
+    const size_t need = qb + tb + 2 * ob + gb + wb;
+    if (need > c->mws_bytes) {
+        VFE_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->mws); c->mws = nullptr; c->mws_bytes = 0;
+        VFE_HIP(hipMalloc(&c->mws, need));
+        c->mws_bytes = need;
+    }
+    char* p = (char*)c->mws;
+    uint8_t* dq = (uint8_t*)p; uint8_t* dt = (uint8_t*)(p + qb);
+    int* di = (int*)(p + qb + tb); int* dd = (int*)(p + qb + tb + ob);
+    uint8_t* dg = (uint8_t*)(p + qb + tb + 2 * ob);
+    void* w = p + qb + tb + 2 * ob + gb;
+    VFE_HIP(hipMemcpyAsync(dq, query, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    if (nt) VFE_HIP(hipMemcpyAsync(dt, train, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = vfe_dev_match_knn2(dq, nq, dt, nt, 0, di, dd, w, wb, c->stream))) return rc;
+    if (good && (rc = vfe_dev_ratio_test(di, dd, nq, ratio, dg, c->stream))) return rc;
+    VFE_HIP(hipMemcpyAsync(idx, di, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(dist, dd, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (good) VFE_HIP(hipMemcpyAsync(good, dg, (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipStreamSynchronize(c->stream));
+    return VFE_OK;
+}
+
+extern "C" int vfe_process_frame(vfe_ctx* c, const uint8_t* data, int rows, int cols, size_t step, int channels,
+                                 int64_t timestamp_ns, int max_corners, double quality, double min_distance,
+                                 vfe_frame_stats* stats) {
+    (void)timestamp_ns;
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    VFE_REQUIRE(max_corners > 0 && max_corners <= c->cfg.max_features, "max_corners exceeds the context's max_features");
+    if (c->have_prev && (c->w != cols || c->h != rows)) c->have_prev = 0; /* size change restarts the stream */
+    const int nxt = c->have_prev ? (c->cur ^ 1) : c->cur;
+    if ((rc = ctx_upload(c, nxt, data, rows, cols, step, channels))) return rc;
+    vfe_dimg pl[CTX_MAX_LK_LEVELS], nl[CTX_MAX_LK_LEVELS];
+    const int nlev = ctx_levels(c, nxt, cols, rows, c->cfg.pyramid_levels - 1, nl);
+    int h_n[2] = {0, 0};
+    if (!c->have_prev) {
+        if ((rc = vfe_dev_build_pyramid(nl, nlev, c->stream))) return rc;
+        if ((rc = vfe_dev_good_features(&nl[0], max_corners, quality, min_distance, nullptr, nullptr, 0, c->pts, nullptr,
+                                        c->n_pts, c->ws, c->ws_bytes, c->stream))) return rc;
+        VFE_HIP(hipMemsetAsync(c->n_tracked, 0, sizeof(int), c->stream));
+    } else {
+        ctx_levels(c, c->cur, cols, rows, c->cfg.pyramid_levels - 1, pl);
+        if ((rc = vfe_dev_frontend_step(pl, nl, nlev, c->pts, c->n_pts, c->n_tracked, max_corners, quality, min_distance,
+                                        c->cfg.win_size, 30, 0.01, 1e-4, c->ws, c->ws_bytes, c->stream))) return rc;
+    }
+    VFE_HIP(hipMemcpyAsync(&h_n[0], c->n_pts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(&h_n[1], c->n_tracked, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipStreamSynchronize(c->stream));
+    c->cur = nxt; c->have_prev = 1; c->w = cols; c->h = rows;
+    if (stats) { stats->n_total = h_n[0]; stats->n_tracked = h_n[1]; stats->n_detected = h_n[0] - h_n[1]; }
+    return VFE_OK;
+}
+
+extern "C" int vfe_get_points(vfe_ctx* c, float* pts_xy, int cap, int* n_out) {
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    VFE_REQUIRE(pts_xy && n_out && cap >= 0, "NULL output");
+    int n = 0;
+    VFE_HIP(hipMemcpyAsync(&n, c->n_pts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipStreamSynchronize(c->stream));
+    if (n > cap) n = cap;
+    if (n > 0) VFE_HIP(hipMemcpy(pts_xy, c->pts, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    *n_out = n;
+    return VFE_OK;
+}

@@ -197,7 +197,8 @@ int fast_detect(const DImg& d, int threshold, int border, int* kps, int cap, int
     uint8_t* rowcnt = (uint8_t*)(ws + L.rowcnt_off);
     uint32_t* rowoff = (uint32_t*)(ws + L.rowoff_off);
     uint32_t* tmp = (uint32_t*)(ws + L.tmp_off);
-    const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
+    const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0) &&
+                         (d.sub_n == 1 || (d.sub_dx % 4 == 0 && d.sub_dy % 4 == 0));
     dim3 grid(total < 2048u ? total : 2048u);
     ProfScope prof(VFE_K_FAST, st);
     if (aligned)
@@ -231,4 +232,132 @@ extern "C" int vfe_dev_fast9(const vfe_dimg* img, int threshold, int* kps, int c
         return VFE_E_NOMEM;
     }
     return fast_detect(to_dimg(img), threshold, 0, kps, cap, counts, (char*)workspace, (hipStream_t)stream);
+}
+
+
+/* ---- grid-bucketed FAST (OpenVINS-style) --------------------------------------------------
+ * FAST runs on every grid cell as an image of its own (3-pixel rim and NMS per cell), the best
+ * `per_cell` of each cell by score (ties: raster order) are offered, cell after cell, to an
+ * occupancy grid of min_px_dist pixels that existing tracks have marked first. */
+__global__ __launch_bounds__(256) void k_fast_grid_select(const int* __restrict__ kps, const int* __restrict__ counts, int ccap,
+                                                          int ncells, int grid_x, int size_x, int size_y, int num_features,
+                                                          int min_px_dist, int ow, int oh, uint8_t* __restrict__ occ_all,
+                                                          const float* __restrict__ seeds, const int* __restrict__ n_seeds,
+                                                          int seed_cap, float* __restrict__ pts, int* __restrict__ scores,
+                                                          int cap, int* __restrict__ out_counts) {
+    __shared__ unsigned long long s_red[4];
+    __shared__ int s_n;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    uint8_t* occ = occ_all + (size_t)b * ow * oh;
+    const int ns = (seeds && n_seeds) ? max(0, min(n_seeds[b], seed_cap)) : 0;
+    const int needed = num_features - ns;
+    if (tid == 0) s_n = 0;
+    if (needed <= 0) { if (tid == 0) out_counts[b] = 0; return; }
+    const int per_cell = (int)((double)needed / (double)ncells) + 1;
+    for (int s = tid; s < ns; s += 256) {
+        const int gx = (int)(seeds[((size_t)b * seed_cap + s) * 2] / (float)min_px_dist);
+        const int gy = (int)(seeds[((size_t)b * seed_cap + s) * 2 + 1] / (float)min_px_dist);
+        if (gx >= 0 && gy >= 0 && gx < ow && gy < oh) occ[gy * ow + gx] = 1;
+    }
+    __syncthreads();
+    for (int r = 0; r < ncells; r++) {
+        const int cb = b * ncells + r;
+        const int n = min(counts[cb], ccap);
+        const int* k = kps + (size_t)cb * ccap * 3;
+        const int x0 = (r % grid_x) * size_x, y0 = (r / grid_x) * size_y;
+        unsigned long long last = ~0ull;
+        for (int it = 0; it < per_cell && it < n; it++) {
+            /* next key below `last`: score descending, then list (raster) order */
+            unsigned long long best = 0;
+            for (int i = tid; i < n; i += 256) {
+                const unsigned long long key = ((unsigned long long)(unsigned)k[3 * i + 2] << 32) | (unsigned)(0x7fffffff - i);
+                if (key < last && key > best) best = key;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(best, o); best = v > best ? v : best; }
+            if ((tid & 63) == 0) s_red[tid >> 6] = best;
+            __syncthreads();
+            best = s_red[0];
+#pragma unroll
+            for (int q = 1; q < 4; q++) best = s_red[q] > best ? s_red[q] : best;
+            if (tid == 0 && best) {
+                const int i = 0x7fffffff - (int)(unsigned)(best & 0xffffffffu);
+                const float x = (float)(k[3 * i] + x0), y = (float)(k[3 * i + 1] + y0);
+                const int gx = (int)(x / (float)min_px_dist), gy = (int)(y / (float)min_px_dist);
+                if (gx >= 0 && gy >= 0 && gx < ow && gy < oh && !occ[gy * ow + gx]) {
+                    occ[gy * ow + gx] = 1;
+                    const int o = s_n;
+                    if (o < cap) {
+                        pts[((size_t)b * cap + o) * 2] = x; pts[((size_t)b * cap + o) * 2 + 1] = y;
+                        scores[(size_t)b * cap + o] = k[3 * i + 2];
+                    }
+                    s_n = o + 1;
+                }
+            }
+            last = best;
+            __syncthreads();
+            if (!best) break;
+        }
+    }
+    if (tid == 0) out_counts[b] = min(s_n, cap);
+}
+
+struct FastGridWs { int size_x, size_y, ccap, ow, oh; size_t kps_off, cnt_off, occ_off, fast_off, total; };
+
+static FastGridWs fast_grid_layout(int w, int h, int batch, int grid_x, int grid_y, int min_px_dist) {
+    FastGridWs L;
+    L.size_x = w / grid_x; L.size_y = h / grid_y;
+    L.ccap = (L.size_x * L.size_y) / 4 + 64;
+    L.ow = (int)((float)w / (float)min_px_dist); L.oh = (int)((float)h / (float)min_px_dist);
+    const int nc = grid_x * grid_y;
+    size_t o = 0;
+    L.kps_off = o; o += align_up((size_t)batch * nc * L.ccap * 3 * sizeof(int), 256);
+    L.cnt_off = o; o += align_up((size_t)batch * nc * sizeof(int), 256);
+    L.occ_off = o; o += align_up((size_t)batch * (size_t)(L.ow > 0 ? L.ow : 1) * (size_t)(L.oh > 0 ? L.oh : 1), 256);
+    L.fast_off = o; o += (L.size_x >= 7 && L.size_y >= 7) ? fast_layout(L.size_x, L.size_y, batch * nc).total : 0;
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t vfe_fast_grid_workspace(int width, int height, int batch, int grid_x, int grid_y, int min_px_dist) {
+    if (width <= 0 || height <= 0 || batch <= 0 || grid_x <= 0 || grid_y <= 0 || min_px_dist <= 0) return 0;
+    return fast_grid_layout(width, height, batch, grid_x, grid_y, min_px_dist).total;
+}
+
+extern "C" int vfe_dev_fast_grid(const vfe_dimg* img, int threshold, int grid_x, int grid_y, int num_features,
+                                 int min_px_dist, const float* seeds_xy, const int* n_seeds, int seed_cap,
+                                 float* pts_xy, int* scores, int cap, int* counts,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = vfe_check_dimg(img, "img");
+    if (rc) return rc;
+    VFE_REQUIRE(threshold >= 1 && threshold <= 254, "threshold must be 1..254");
+    VFE_REQUIRE(grid_x > 0 && grid_y > 0 && grid_x * grid_y <= 4096 && num_features > 0 && min_px_dist > 0, "bad grid parameters");
+    VFE_REQUIRE(pts_xy && scores && counts && workspace && cap > 0, "NULL output or workspace");
+    VFE_REQUIRE(!seeds_xy == !n_seeds, "seeds_xy and n_seeds go together");
+    VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const FastGridWs L = fast_grid_layout(img->width, img->height, img->batch, grid_x, grid_y, min_px_dist);
+    if (workspace_bytes < L.total) {
+        vfe_set_error("workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+        return VFE_E_NOMEM;
+    }
+    if (L.size_x < 7 || L.size_y < 7 || L.ow <= 0 || L.oh <= 0) {
+        VFE_HIP(hipMemsetAsync(counts, 0, (size_t)img->batch * sizeof(int), st));
+        return VFE_OK;
+    }
+    char* ws = (char*)workspace;
+    const int nc = grid_x * grid_y;
+    DImg cells = to_dimg(img);
+    cells.w = L.size_x; cells.h = L.size_y; cells.batch = img->batch * nc;
+    cells.sub_n = nc; cells.sub_gx = grid_x; cells.sub_dx = L.size_x; cells.sub_dy = (size_t)L.size_y * img->pitch;
+    int* ckps = (int*)(ws + L.kps_off);
+    int* ccnt = (int*)(ws + L.cnt_off);
+    if ((rc = fast_detect(cells, threshold, 0, ckps, L.ccap, ccnt, ws + L.fast_off, st))) return rc;
+    VFE_HIP(hipMemsetAsync(ws + L.occ_off, 0, (size_t)img->batch * L.ow * L.oh, st));
+    ProfScope prof(VFE_K_FAST, st);
+    hipLaunchKernelGGL(k_fast_grid_select, dim3(img->batch), dim3(256), 0, st, ckps, ccnt, L.ccap, nc, grid_x, L.size_x, L.size_y,
+                       num_features, min_px_dist, L.ow, L.oh, (uint8_t*)(ws + L.occ_off), seeds_xy, n_seeds,
+                       seeds_xy ? seed_cap : 0, pts_xy, scores, cap, counts);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
 }
