@@ -12,7 +12,12 @@ HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fas
 HIP_SRCS = $(wildcard $(CSRC)/*.hip)
 HIP_HDRS = $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/vfe.h
 
-all: $(LIBDIR)/libvfe_synth.so $(LIBDIR)/libvfe.so oracle
+HOST = vi_slam_amd/host
+HOST_SRCS = $(wildcard $(HOST)/src/*.cpp)
+HOST_HDRS = $(wildcard $(HOST)/include/*/*.hpp) $(wildcard $(HOST)/include/*/*/*.hpp) include/vfe.h
+CPP_TESTS = $(patsubst tests/cpp/%.cpp,tests/cpp/bin/%,$(wildcard tests/cpp/*.cpp))
+
+all: $(LIBDIR)/libvfe_synth.so $(LIBDIR)/libvfe.so $(LIBDIR)/libvi_slam_amd.so $(CPP_TESTS) oracle
 
 $(LIBDIR):
 	mkdir -p $(LIBDIR)
@@ -23,6 +28,15 @@ $(LIBDIR)/libvfe_synth.so: $(CSRC)/synth.cpp | $(LIBDIR)
 $(LIBDIR)/libvfe.so: $(HIP_SRCS) $(HIP_HDRS) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
 
+# host side: SLAMEngine + framework adapters (C++17), linked against libvfe.so next to it
+$(LIBDIR)/libvi_slam_amd.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/libvfe.so
+	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -I$(HOST)/include -Iinclude -shared -o $@ $(HOST_SRCS) -L$(LIBDIR) -lvfe -Wl,-rpath,'$$ORIGIN' -lpthread
+
+# lifecycle tests in the reference's style (plain main(), exit code 1 on failure)
+tests/cpp/bin/%: tests/cpp/%.cpp $(LIBDIR)/libvi_slam_amd.so
+	@mkdir -p tests/cpp/bin
+	$(CXX) -O1 -std=c++17 -Wall -I$(HOST)/include -Iinclude -o $@ $< -L$(LIBDIR) -lvi_slam_amd -lvfe -Wl,-rpath,'$$ORIGIN/../../../$(LIBDIR)' -lpthread
+
 oracle:
 	$(MAKE) -C oracle libvfe_oracle.so
 
@@ -31,6 +45,7 @@ oracle-fast:
 
 clean:
 	rm -f $(LIBDIR)/*.so
+	rm -rf tests/cpp/bin
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle oracle-fast clean

@@ -1,0 +1,101 @@
+"""GPU: the drop-in path end to end -- SLAMEngine -> adapter -> C ABI -> HIP kernels -- in the
+shape of the reference's streaming fixture (tests/e2e/e2e_test_fixture.cpp:115-171), with every
+per-frame result checked against the CPU oracle of the OpenCV call the reference adapter makes."""
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+from vi_slam_amd import engine as eng
+from vi_slam_amd import synth
+from test_host_layer import BASALT_YAML, OPENVINS_YAML, ORB_YAML, VINS_YAML, write
+
+pytestmark = pytest.mark.gpu
+W, H = 752, 480
+
+
+def make_engine(tmp_path, ftype, yaml_text):
+    e = eng.SLAMEngine()
+    assert e.select_framework(ftype)
+    assert e.initialize(write(tmp_path, "cfg.yaml", yaml_text))
+    assert e.load_calibration(write(tmp_path, "calib.yaml", "cam0: {}\n"))
+    return e
+
+
+def test_openvins_and_basalt_reproduce_good_features_to_track(cuda, tmp_path):
+    frames = [synth.scene(synth.BASE_SEED + 50, W, H, t) for t in range(3)]
+    for ftype, text, (n, q, d) in [(eng.OPENVINS, OPENVINS_YAML, (200, 0.01, 10)), (eng.BASALT, BASALT_YAML, (200, 0.7 * 0.01, 10))]:
+        e = make_engine(tmp_path, ftype, text)
+        lat, counts = eng.run_streaming(e, frames)
+        assert e.frontend_error() == ""
+        for f, c in zip(frames, counts):
+            ref, _ = ora.good_features(f, n, q, d)
+            assert c == len(ref)
+        assert np.array_equal(e.points(), ora.good_features(frames[-1], n, q, d)[0])
+        assert e.status() == eng.TRACKING and e.pose_callbacks() == len(frames)
+        e.close()
+
+
+def test_bgr_frames_like_the_receiver_emits(cuda, tmp_path):
+    """pc_client's receiver hands over CV_8UC3 frames (pc_client/src/webrtc_receiver.cpp:110)."""
+    g = synth.scene(synth.BASE_SEED + 51, 640, 480, 0)
+    bgr = np.stack([g, g, g], axis=2)
+    e = make_engine(tmp_path, eng.OPENVINS, OPENVINS_YAML)
+    _, counts = eng.run_streaming(e, [bgr])
+    ref, _ = ora.good_features(ora.bgr2gray(bgr), 200, 0.01, 10)
+    assert counts[0] == len(ref) and np.array_equal(e.points(), ref)
+    e.close()
+
+
+def test_orbslam3_state_machine_on_keypoint_counts(cuda, tmp_path):
+    frames = [synth.scene(synth.BASE_SEED + 52, W, H, t) for t in range(11)]
+    e = make_engine(tmp_path, eng.ORB_SLAM3, ORB_YAML)
+    lat, counts = eng.run_streaming(e, frames)
+    k, _ = ora.orb_extract(frames[0], 1200)
+    assert counts[0] == len(k)
+    k, _ = ora.orb_extract(frames[-1], 1200)
+    assert counts[-1] == len(k)
+    assert np.array_equal(e.points(), np.stack([k["x"], k["y"]], axis=1))
+    # NOT_INITIALIZED until the 10th frame with > 100 keypoints, then OK -> TRACKING with a pose
+    assert e.status() == eng.TRACKING and e.pose_callbacks() == 2
+    # constant frames: < 30 keypoints -> RECENTLY_LOST -> LOST
+    blank = np.full((H, W), 128, np.uint8)
+    eng.run_streaming(e, [blank, blank], t0_ns=10_000_000_000, warm_imu_s=0.0)
+    assert e.tracked_count() == 0 and e.status() == eng.LOST
+    e.close()
+
+
+def test_vins_mono_stream_tracks_and_refills(cuda, tmp_path):
+    """configs[0]: 752x480, 150 Shi-Tomasi corners (min_dist 30) + pyramidal KLT via vins_mono.yaml."""
+    frames = [synth.scene(synth.BASE_SEED + 53, W, H, t) for t in range(4)]
+    e = make_engine(tmp_path, eng.VINS_MONO, VINS_YAML)
+    ref = None
+    for t, f in enumerate(frames):
+        e.process_image(f, 10**9 + t * 10**8)
+        if ref is None:
+            ref, _ = ora.good_features(f, 150, 0.01, 30)
+        else:
+            nxt, st, _ = ora.klt_track(frames[t - 1], f, ref, 21, 3)
+            r = np.rint(nxt)
+            keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < W - 1) & (r[:, 1] >= 1) & (r[:, 1] < H - 1)
+            tracked = nxt[keep]
+            ref = tracked
+            if 150 - len(tracked) > 0:
+                new, _ = ora.good_features(f, 150 - len(tracked), 0.01, 30, seeds=tracked)
+                ref = np.concatenate([tracked, new]) if len(new) else tracked
+        assert e.tracked_count() == len(ref)
+        assert np.array_equal(e.points().view(np.uint32), ref.view(np.uint32))
+    assert e.frontend_error() == ""
+    # the reference's VINS estimator never yields a pose: TRACKING after calibration, LOST after the first frame
+    assert e.status() == eng.LOST and e.pose_callbacks() == 0
+    e.close()
+
+
+def test_streaming_latency_shape_of_the_reference_e2e(cuda, tmp_path):
+    """test_basic_streaming's assertion (avg per-frame latency < 100 ms) on its 640x480 noise frames."""
+    frames = [synth.noise(1000 + i, 640, 480) for i in range(20)]
+    e = make_engine(tmp_path, eng.OPENVINS, OPENVINS_YAML)
+    lat, counts = eng.run_streaming(e, frames)
+    assert e.frontend_error() == ""
+    assert np.mean(lat[2:]) < 100.0, lat
+    assert all(c > 0 for c in counts)
+    e.close()

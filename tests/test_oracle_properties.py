@@ -1,0 +1,201 @@
+"""CPU: known answers and properties of the oracle that can be derived without OpenCV
+(the only kind of known answer the reference's own fixtures allow: a constant frame,
+tests/test_slam_engine.cpp:94, yields no features)."""
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+from oracle import oracle as ora
+from vi_slam_amd import synth
+
+W, H = 320, 240
+
+
+@pytest.fixture(scope="module")
+def img():
+    return synth.scene(synth.BASE_SEED + 40, W, H, 0)
+
+
+def test_constant_frame_yields_nothing():
+    c = np.full((480, 640), 128, np.uint8)
+    assert len(ora.good_features(c, 200, 0.01, 10)[0]) == 0
+    assert len(ora.fast9(c, 20)) == 0
+    assert len(ora.orb_extract(c, 1200)[0]) == 0
+    assert (ora.min_eigen_map(c) == 0).all()
+
+
+def test_pyr_down_close_to_float_gaussian(img):
+    k = np.array([1, 4, 6, 4, 1], float) / 16
+    ref = ndi.convolve1d(ndi.convolve1d(img.astype(float), k, axis=0, mode="mirror"), k, axis=1, mode="mirror")[::2, ::2]
+    out = ora.pyr_down(img)
+    assert out.shape == ((H + 1) // 2, (W + 1) // 2)
+    assert np.abs(out - ref).max() <= 0.5 + 1e-9
+    odd = ora.pyr_down(img[:201, :301])
+    assert odd.shape == (101, 151)
+
+
+def test_lk_max_level_stops_before_small_levels():
+    assert ora.lk_max_level(752, 480, 21, 3) == 3
+    assert ora.lk_max_level(100, 80, 21, 5) == 1   # 50x40 ok, 25x20 <= 21 in height stops
+    assert ora.lk_max_level(40, 40, 21, 3) == 0
+
+
+def test_gauss7_kernel_and_blur(img):
+    k = ora.gauss7_kernel()
+    assert list(k) == [18, 34, 48, 56, 48, 34, 18] and k.sum() == 256
+    ref = ndi.convolve1d(ndi.convolve1d(img.astype(float), k / 256., axis=0, mode="mirror"), k / 256., axis=1, mode="mirror")
+    assert np.abs(ora.gauss7(img) - ref).max() <= 0.5 + 1e-9
+
+
+def test_resize_exact_identity_and_range(img):
+    assert np.array_equal(ora.resize_linear_exact(img, W, H), img)
+    r = ora.resize_linear_exact(img, 267, 200)
+    assert r.shape == (200, 267) and r.min() >= img.min() and r.max() <= img.max()
+
+
+def test_bgr2gray_weights():
+    px = np.zeros((1, 3, 3), np.uint8)
+    px[0, 0] = (255, 0, 0); px[0, 1] = (0, 255, 0); px[0, 2] = (0, 0, 255)
+    assert list(ora.bgr2gray(px)[0]) == [29, 150, 76]
+    g = np.full((4, 4, 3), 77, np.uint8)
+    assert (ora.bgr2gray(g) == 77).all()
+
+
+def test_good_features_contract(img):
+    for n, q, d in [(50, 0.01, 10), (500, 0.01, 5), (100, 0.05, 17.5)]:
+        xy, sc = ora.good_features(img, n, q, d)
+        assert len(xy) <= n
+        assert (np.diff(sc) <= 0).all()                      # score-descending
+        assert (xy[:, 0] >= 1).all() and (xy[:, 0] <= W - 2).all() and (xy[:, 1] >= 1).all() and (xy[:, 1] <= H - 2).all()
+        dd = np.linalg.norm(xy[:, None] - xy[None], axis=2) + np.eye(len(xy)) * 1e9
+        assert dd.min() >= d
+        eig = ora.min_eigen_map(img)
+        assert np.array_equal(sc, eig[xy[:, 1].astype(int), xy[:, 0].astype(int)])
+        assert (sc > np.float32(float(eig.max()) * q)).all()
+    # a prefix of a longer list: the greedy walk only depends on higher-ranked candidates
+    a, _ = ora.good_features(img, 30, 0.01, 10)
+    b, _ = ora.good_features(img, 80, 0.01, 10)
+    assert np.array_equal(a, b[:30])
+
+
+def test_good_features_seeds_keep_distance(img):
+    seeds, _ = ora.good_features(img, 20, 0.01, 15)
+    xy, _ = ora.good_features(img, 100, 0.01, 15, seeds=seeds + np.float32(0.3))
+    dd = np.linalg.norm(xy[:, None] - np.rint(seeds + np.float32(0.3))[None], axis=2)
+    assert dd.min() >= 15 and len(xy) > 0
+
+
+def test_klt_recovers_known_translation():
+    a = synth.scene(synth.BASE_SEED + 41, W, H, 0, vx=0, vy=0, rot_deg=0)
+    b = synth.scene(synth.BASE_SEED + 41, W, H, 1, vx=2.25, vy=-1.5, rot_deg=0)
+    pts, _ = ora.good_features(a, 60, 0.01, 12)
+    out, st, err = ora.klt_track(a, b, pts, 21, 2)
+    inner = (pts[:, 0] > 30) & (pts[:, 0] < W - 30) & (pts[:, 1] > 30) & (pts[:, 1] < H - 30) & st.astype(bool)
+    assert inner.sum() > 20
+    flow = (out - pts)[inner]
+    assert np.abs(np.median(flow, axis=0) - [-2.25, 1.5]).max() < 0.05
+    assert (err[inner] >= 0).all()
+    # identical frames: zero flow, zero error
+    out0, st0, err0 = ora.klt_track(a, a, pts, 21, 2)
+    assert st0.all() and np.abs(out0 - pts).max() < 1e-3 and np.abs(err0).max() == 0
+
+
+def test_klt_status_for_points_outside():
+    a = synth.scene(synth.BASE_SEED + 41, W, H, 0)
+    pts = np.array([[-40.0, 10.0], [W + 30.0, 5.0], [5.0, H + 40.0]], np.float32)
+    _, st, err = ora.klt_track(a, a, pts, 21, 2)
+    assert not st.any() and (err == 0).all()
+
+
+def test_fast_on_synthetic_corner():
+    im = np.full((40, 40), 50, np.uint8)
+    im[20:, 20:] = 200           # one bright quadrant: corner responses only around (20, 20)
+    kn = ora.fast9(im, 20, nms=False)
+    assert len(kn) >= 1
+    assert (np.abs(kn[:, :2] - 20) <= 3).all()
+    assert (kn[:, 2] >= 20).all()
+    # with suppression a plateau of equal scores has no strict maximum: fewer (possibly zero) survive
+    assert len(ora.fast9(im, 20)) <= len(kn)
+    # score = largest threshold that still detects the corner
+    x, y, s = kn[0]
+    assert len([p for p in ora.fast9(im, int(s), nms=False) if p[0] == x and p[1] == y]) == 1
+    assert len([p for p in ora.fast9(im, int(s) + 1, nms=False) if p[0] == x and p[1] == y]) == 0
+    # the corner pixel itself: 11 of 16 circle pixels are darker by 150
+    assert any(p[0] == 20 and p[1] == 20 and p[2] == 149 for p in kn)
+
+
+def test_fast_raster_order_and_border(img):
+    k = ora.fast9(img, 15)
+    lin = k[:, 1] * W + k[:, 0]
+    assert (np.diff(lin) > 0).all()
+    assert k[:, 0].min() >= 3 and k[:, 0].max() <= W - 4 and k[:, 1].min() >= 3 and k[:, 1].max() <= H - 4
+
+
+def test_fast_grid_contract(img):
+    xy, sc = ora.fast_grid(img, 15, 4, 3, 60, 8)
+    assert 0 < len(xy) <= 60 + 12
+    cells = (xy / 8).astype(int)
+    assert len({(a, b) for a, b in cells}) == len(xy)     # one point per occupancy cell
+
+
+def test_orb_quotas_and_levels():
+    assert list(ora.orb_quotas(2000)) == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert list(ora.orb_quotas(1200)) == [261, 217, 181, 151, 126, 105, 87, 72]
+    wh, sc = ora.orb_level_sizes(752, 480)
+    assert [tuple(x) for x in wh] == [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]
+    assert sc[0] == 1.0 and abs(sc[7] - 1.2 ** 7) < 1e-5
+
+
+def test_orb_contract():
+    im = synth.scene(synth.BASE_SEED + 42, 640, 480, 0)
+    k, d = ora.orb_extract(im, 500)
+    assert 250 < len(k) <= 500 + 64 and d.shape == (len(k), 32)
+    key = k["octave"].astype(np.int64) * 10**8 + k["ly"].astype(np.int64) * 10**4 + k["lx"]
+    assert (np.diff(key) > 0).all()                        # canonical (octave, y, x) order, no duplicates
+    wh, sc = ora.orb_level_sizes(640, 480)
+    for o in range(8):
+        m = k["octave"] == o
+        assert (k["lx"][m] >= 31).all() and (k["lx"][m] < wh[o, 0] - 31).all()
+        assert (k["ly"][m] >= 31).all() and (k["ly"][m] < wh[o, 1] - 31).all()
+        assert np.allclose(k["size"][m], 31 * sc[o])
+    assert (k["angle"] >= 0).all() and (k["angle"] < 360).all()
+    pop = np.unpackbits(d, axis=1).sum(axis=1)
+    assert 100 < pop.mean() < 156                          # descriptors are roughly balanced
+
+
+def test_orb_descriptor_rotation_invariance():
+    """Steering: the descriptor of a patch and of its 90-degree rotation stay close."""
+    im = synth.scene(synth.BASE_SEED + 43, 480, 480, 0)
+    k0, d0 = ora.orb_extract(im, 300, nlevels=1)
+    k1, d1 = ora.orb_extract(np.ascontiguousarray(np.rot90(im)), 300, nlevels=1)
+    # rot90 (counter-clockwise): (x, y) -> (y, W-1-x)
+    pos1 = {(int(a), int(b)): i for i, (a, b) in enumerate(zip(k1["lx"], k1["ly"]))}
+    dists = []
+    for i, (x, y) in enumerate(zip(k0["lx"], k0["ly"])):
+        j = pos1.get((int(y), 479 - int(x)))
+        if j is not None:
+            dists.append(np.unpackbits(d0[i] ^ d1[j]).sum())
+    assert len(dists) > 50 and np.median(dists) < 40
+
+
+def test_match_contract_and_ties():
+    q = synth.descriptors(1, 50)
+    t = synth.descriptors(2, 400)
+    t[10] = q[3]; t[200] = q[3]            # exact duplicates: lower index first
+    t[77] = synth.flip_bits(5, q[8], 12)
+    idx, dist = ora.match_knn2(q, t)
+    assert list(idx[3]) == [10, 200] and list(dist[3]) == [0, 0]
+    assert idx[8, 0] == 77 and dist[8, 0] == 12
+    full = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(axis=2)
+    assert np.array_equal(dist[:, 0], full.min(axis=1))
+    good = ora.ratio_test(idx, dist, 0.7)
+    assert not good[3] and good[8]
+    i1, d1 = ora.match_knn2(q, t[:1])
+    assert (i1[:, 1] == -1).all() and not ora.ratio_test(i1, d1, 0.7).any()
+    i0, d0 = ora.match_knn2(q, np.zeros((0, 32), np.uint8))
+    assert (i0 == -1).all()
+
+
+def test_equalize_hist_spreads_range(img):
+    e = ora.equalize_hist((img // 4 + 60).astype(np.uint8))
+    assert e.min() == 0 and e.max() == 255

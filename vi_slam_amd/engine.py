@@ -1,0 +1,154 @@
+"""Python view of the C++ host layer (libvi_slam_amd.so: SLAMEngine + framework adapters).
+
+Mirrors the reference's facade (include/slam/slam_engine.hpp:71-242) for harnesses and tests;
+images are numpy arrays standing in for cv::Mat.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvi_slam_amd.so")
+_LIB = None
+
+VINS_MONO, OPENVINS, ORB_SLAM3, BASALT = range(4)
+UNINITIALIZED, INITIALIZING, TRACKING, LOST, RELOCALIZATION = range(5)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: run `make`")
+        L = C.CDLL(LIB_PATH)
+        L.vis_engine_create.restype = C.c_void_p
+        for name, args, res in [
+            ("vis_engine_destroy", [C.c_void_p], None),
+            ("vis_engine_select", [C.c_void_p, C.c_int], C.c_int),
+            ("vis_engine_current", [C.c_void_p], C.c_int),
+            ("vis_engine_initialize", [C.c_void_p, C.c_char_p], C.c_int),
+            ("vis_engine_load_calibration", [C.c_void_p, C.c_char_p], C.c_int),
+            ("vis_engine_process_image", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int64], None),
+            ("vis_engine_process_imu", [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)], None),
+            ("vis_engine_status", [C.c_void_p], C.c_int),
+            ("vis_engine_pose", [C.c_void_p, C.POINTER(C.c_double)], C.c_int),
+            ("vis_engine_tracked_count", [C.c_void_p], C.c_int),
+            ("vis_engine_pose_callbacks", [C.c_void_p], C.c_long),
+            ("vis_engine_status_callbacks", [C.c_void_p], C.c_long),
+            ("vis_engine_last_status", [C.c_void_p], C.c_int),
+            ("vis_engine_reset", [C.c_void_p], None),
+            ("vis_engine_shutdown", [C.c_void_p], None),
+            ("vis_engine_frontend_error", [C.c_void_p], C.c_char_p),
+            ("vis_engine_points", [C.c_void_p, C.c_void_p, C.c_int], C.c_int),
+            ("vis_engine_config_value", [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)], C.c_int),
+        ]:
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = res
+        _LIB = L
+    return _LIB
+
+
+class SLAMEngine:
+    def __init__(self):
+        self._h = C.c_void_p(lib().vis_engine_create())
+
+    def close(self):
+        if self._h:
+            lib().vis_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def select_framework(self, t):
+        return bool(lib().vis_engine_select(self._h, t))
+
+    def current_framework(self):
+        return lib().vis_engine_current(self._h)
+
+    def initialize(self, config_path):
+        return bool(lib().vis_engine_initialize(self._h, str(config_path).encode()))
+
+    def load_calibration(self, calib_path):
+        return bool(lib().vis_engine_load_calibration(self._h, str(calib_path).encode()))
+
+    def process_image(self, image, timestamp_ns):
+        if image is None:
+            lib().vis_engine_process_image(self._h, None, 0, 0, 0, 1, timestamp_ns)
+            return
+        a = np.ascontiguousarray(image, np.uint8)
+        ch = 1 if a.ndim == 2 else a.shape[2]
+        lib().vis_engine_process_image(self._h, a.ctypes.data, a.shape[0], a.shape[1], a.strides[0], ch, timestamp_ns)
+
+    def process_imu(self, timestamp_ns, acc, gyro):
+        a = (C.c_double * 3)(*acc)
+        g = (C.c_double * 3)(*gyro)
+        lib().vis_engine_process_imu(self._h, timestamp_ns, a, g)
+
+    def status(self):
+        return lib().vis_engine_status(self._h)
+
+    def pose(self):
+        out = (C.c_double * 8)()
+        ok = lib().vis_engine_pose(self._h, out)
+        return bool(ok), list(out)
+
+    def tracked_count(self):
+        return lib().vis_engine_tracked_count(self._h)
+
+    def pose_callbacks(self):
+        return lib().vis_engine_pose_callbacks(self._h)
+
+    def status_callbacks(self):
+        return lib().vis_engine_status_callbacks(self._h)
+
+    def last_status(self):
+        return lib().vis_engine_last_status(self._h)
+
+    def reset(self):
+        lib().vis_engine_reset(self._h)
+
+    def shutdown(self):
+        lib().vis_engine_shutdown(self._h)
+
+    def frontend_error(self):
+        return lib().vis_engine_frontend_error(self._h).decode()
+
+    def points(self, cap=8192):
+        out = np.zeros((cap, 2), np.float32)
+        n = lib().vis_engine_points(self._h, out.ctypes.data, cap)
+        return out[:n].copy()
+
+    def config_value(self, key):
+        v = C.c_double(0)
+        if not lib().vis_engine_config_value(self._h, key.encode(), C.byref(v)):
+            raise KeyError(key)
+        return v.value
+
+
+def run_streaming(engine, frames, imu_per_frame=10, frame_dt_ns=100_000_000, t0_ns=2_000_000_000, warm_imu_s=1.5):
+    """Counterpart of the reference's E2ETestFixture::runStreamingTest
+    (tests/e2e/e2e_test_fixture.cpp:115-171): per frame, feed `imu_per_frame` IMU samples then the
+    image, and record the wall-clock latency of that iteration in milliseconds.  IMU samples for
+    `warm_imu_s` seconds are fed first so that the adapters' 1-second initialisation gate is open.
+    Returns (latencies_ms, tracked_counts)."""
+    import time
+    t = t0_ns - int(warm_imu_s * 1e9)
+    while t < t0_ns:
+        engine.process_imu(t, (0.0, 0.0, 9.81), (0.0, 0.0, 0.0))
+        t += 5_000_000
+    lat, counts = [], []
+    for i, f in enumerate(frames):
+        ts = t0_ns + i * frame_dt_ns
+        s = time.perf_counter()
+        for k in range(imu_per_frame):
+            engine.process_imu(ts - frame_dt_ns + (k + 1) * frame_dt_ns // imu_per_frame, (0.0, 0.0, 9.81), (0.0, 0.0, 0.01))
+        engine.process_image(f, ts)
+        lat.append((time.perf_counter() - s) * 1e3)
+        counts.append(engine.tracked_count())
+    return lat, counts

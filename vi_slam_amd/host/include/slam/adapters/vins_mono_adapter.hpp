@@ -1,0 +1,45 @@
+#ifndef VI_SLAM_AMD_VINS_MONO_ADAPTER_HPP
+#define VI_SLAM_AMD_VINS_MONO_ADAPTER_HPP
+#include "slam/adapters/adapter_base.hpp"
+
+namespace vi_slam {
+
+/* Front-end keys of config/vins_mono.yaml:38-39,91-104.  The reference adapter opens the file
+ * but reads none of them (src/slam/adapters/vins_mono_adapter.cpp:192-201); they are parsed
+ * here so that the file drives the GPU front-end. */
+struct VINSMonoConfig {
+    int imageWidth = 752;
+    int imageHeight = 480;
+    int maxCnt = 150;        /* max_cnt: features to keep */
+    int minDist = 30;        /* min_dist: pixels between features */
+    int freq = 10;
+    double fThreshold = 1.0; /* F_threshold: RANSAC threshold (not used by the front-end) */
+    bool equalize = true;
+    int pyramidLevels = 4;   /* upstream VINS-Mono calls calcOpticalFlowPyrLK with maxLevel 3 */
+};
+
+/* VINS-Mono adapter (reference: include/slam/adapters/vins_mono_adapter.hpp,
+ * src/slam/adapters/vins_mono_adapter.cpp:94-122).  The reference estimator ignores the image;
+ * this one runs the VINS-style front-end on it: KLT from the previous frame, refill with
+ * Shi-Tomasi corners up to max_cnt at min_dist.  Pose and status keep the reference's
+ * placeholder semantics (no pose is ever produced). */
+class VINSMonoAdapter : public AdapterBase {
+public:
+    VINSMonoAdapter();
+    ~VINSMonoAdapter() override;
+    VINSMonoConfig getConfig() const { return config_; }
+    /* current tracked points (x, y pairs) */
+    std::vector<float> getTrackedPoints();
+
+protected:
+    void configKey(const std::string& section, const std::string& key, const std::string& value) override;
+    void configDone() override;
+    int feedImage(const ImageView& image, int64_t timestampNs, const std::vector<IMUSample>& imu) override;
+    bool estimatePose(Pose6DoF& pose, int64_t timestampNs) override { (void)pose; (void)timestampNs; return false; }
+
+private:
+    VINSMonoConfig config_;
+};
+
+}  // namespace vi_slam
+#endif

@@ -1,0 +1,40 @@
+#ifndef VI_SLAM_AMD_GPU_FRONTEND_HPP
+#define VI_SLAM_AMD_GPU_FRONTEND_HPP
+/* RAII owner of a vfe_ctx (include/vfe.h): the only place the adapters touch the GPU library.
+ * Created lazily on the first image that reaches the front-end, so adapter lifecycle calls
+ * work on machines without a GPU, as the reference's do without touching OpenCV. */
+#include "slam/image_view.hpp"
+#include "vfe.h"
+#include <string>
+#include <vector>
+
+namespace vi_slam {
+
+class GpuFrontEnd {
+public:
+    GpuFrontEnd() = default;
+    ~GpuFrontEnd();
+    GpuFrontEnd(const GpuFrontEnd&) = delete;
+    GpuFrontEnd& operator=(const GpuFrontEnd&) = delete;
+
+    void configure(int maxFeatures, int pyramidLevels, int winSize, int orbLevels, int device = 0);
+    /* each returns false and records lastError() on failure; never throws */
+    bool detectShiTomasi(const ImageView& img, int maxCorners, double quality, double minDistance, std::vector<float>& xy);
+    bool orbExtract(const ImageView& img, int nFeatures, float scaleFactor, int nLevels, int fastThreshold,
+                    std::vector<vfe_orb_kp>& kps, std::vector<uint8_t>& desc);
+    bool processFrame(const ImageView& img, int64_t ts, int maxCorners, double quality, double minDistance, vfe_frame_stats& st);
+    bool points(std::vector<float>& xy);
+    void reset();
+    void release();
+    const std::string& lastError() const { return error_; }
+
+private:
+    bool ensure(const ImageView& img);
+    bool fail(int rc);
+    vfe_ctx* ctx_ = nullptr;
+    vfe_config cfg_{0, 0, 0, 1000, 4, 21, 0};
+    std::string error_;
+};
+
+}  // namespace vi_slam
+#endif

@@ -1,0 +1,33 @@
+#ifndef VI_SLAM_AMD_I_SLAM_FRAMEWORK_HPP
+#define VI_SLAM_AMD_I_SLAM_FRAMEWORK_HPP
+/* The adapter contract, method for method as in the reference
+ * (include/slam/i_slam_framework.hpp:30-110); only the image parameter type differs
+ * (ImageView instead of cv::Mat, see image_view.hpp). */
+#include "common/types.hpp"
+#include "slam/image_view.hpp"
+#include <string>
+#include <vector>
+
+namespace vi_slam {
+
+class ISLAMFramework {
+public:
+    virtual ~ISLAMFramework() = default;
+    virtual bool initialize(const std::string& configPath) = 0;
+    virtual bool loadCalibration(const std::string& calibPath) = 0;
+    virtual void processImage(const ImageView& image, int64_t timestampNs) = 0;
+    virtual void processIMU(const IMUSample& imu) = 0;
+    virtual bool getPose(Pose6DoF& pose) const = 0;
+    virtual TrackingStatus getStatus() const = 0;
+    virtual std::vector<MapPoint> getMapPoints() const = 0;
+    virtual void reset() = 0;
+    virtual void shutdown() = 0;
+    /* additions shared by all adapters of this build (reference: per-adapter
+     * getTrackedFeatureCount, include/slam/adapters/openvins_adapter.hpp:105) */
+    virtual int getTrackedFeatureCount() const = 0;
+    /* last front-end (GPU) error message, empty if none: process calls never throw */
+    virtual std::string getFrontEndError() const = 0;
+};
+
+}  // namespace vi_slam
+#endif

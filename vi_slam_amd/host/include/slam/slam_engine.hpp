@@ -1,0 +1,57 @@
+#ifndef VI_SLAM_AMD_SLAM_ENGINE_HPP
+#define VI_SLAM_AMD_SLAM_ENGINE_HPP
+/* Facade with the reference's public surface (include/slam/slam_engine.hpp:35-242): framework
+ * selection, mutex-serialised dispatch, pose / status callbacks.  Unlike the reference, whose
+ * factory returns nullptr for three of the four types (src/slam/slam_engine.cpp:207-229),
+ * every SLAMFrameworkType constructs here.  ROS / ZMQ fan-out is not part of the front-end. */
+#include "slam/i_slam_framework.hpp"
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+
+namespace vi_slam {
+
+enum class SLAMFrameworkType { VINS_MONO, OPENVINS, ORB_SLAM3, BASALT };
+using PoseCallback = std::function<void(const Pose6DoF&)>;
+using StatusCallback = std::function<void(TrackingStatus)>;
+
+class SLAMEngine {
+public:
+    SLAMEngine();
+    ~SLAMEngine();
+    SLAMEngine(const SLAMEngine&) = delete;
+    SLAMEngine& operator=(const SLAMEngine&) = delete;
+
+    bool selectFramework(SLAMFrameworkType type);
+    SLAMFrameworkType getCurrentFramework() const;
+    bool initialize(const std::string& configPath);
+    bool loadCalibration(const std::string& calibPath);
+    void processImage(const ImageView& image, int64_t timestampNs);
+    void processIMU(const IMUSample& imu);
+    bool getPose(Pose6DoF& pose) const;
+    TrackingStatus getStatus() const;
+    std::vector<MapPoint> getMapPoints() const;
+    void reset();
+    void shutdown();
+    void setPoseCallback(PoseCallback callback);
+    void setStatusCallback(StatusCallback callback);
+    /* additions of this build */
+    int getTrackedFeatureCount() const;
+    std::string getFrontEndError() const;
+    ISLAMFramework* framework() { return framework_.get(); }
+
+private:
+    std::unique_ptr<ISLAMFramework> createFramework(SLAMFrameworkType type);
+    void invokePoseCallback(const Pose6DoF& pose);
+    void invokeStatusCallback(TrackingStatus status);
+    std::unique_ptr<ISLAMFramework> framework_;
+    SLAMFrameworkType currentType_;
+    PoseCallback poseCallback_;
+    StatusCallback statusCallback_;
+    mutable std::mutex frameworkMutex_, callbackMutex_;
+    bool initialized_;
+};
+
+}  // namespace vi_slam
+#endif

@@ -1,0 +1,124 @@
+/* Flat C view of SLAMEngine for non-C++ harnesses (the Python streaming harness and tests). */
+#include "slam/slam_engine.hpp"
+#include "slam/adapters/openvins_adapter.hpp"
+#include "slam/adapters/basalt_adapter.hpp"
+#include "slam/adapters/orbslam3_adapter.hpp"
+#include "slam/adapters/vins_mono_adapter.hpp"
+#include <cstring>
+
+using namespace vi_slam;
+
+namespace {
+struct Handle {
+    SLAMEngine engine;
+    long poseCalls = 0, statusCalls = 0;
+    int lastStatus = 0;
+    std::string err;
+};
+}  // namespace
+
+extern "C" {
+
+void* vis_engine_create() {
+    Handle* h = new Handle;
+    h->engine.setPoseCallback([h](const Pose6DoF&) { h->poseCalls++; });
+    h->engine.setStatusCallback([h](TrackingStatus s) { h->statusCalls++; h->lastStatus = (int)s; });
+    return h;
+}
+void vis_engine_destroy(void* p) { delete static_cast<Handle*>(p); }
+int vis_engine_select(void* p, int type) {
+    if (type < 0 || type > 3) return 0;
+    return static_cast<Handle*>(p)->engine.selectFramework((SLAMFrameworkType)type) ? 1 : 0;
+}
+int vis_engine_current(void* p) { return (int)static_cast<Handle*>(p)->engine.getCurrentFramework(); }
+int vis_engine_initialize(void* p, const char* cfg) { return static_cast<Handle*>(p)->engine.initialize(cfg) ? 1 : 0; }
+int vis_engine_load_calibration(void* p, const char* calib) { return static_cast<Handle*>(p)->engine.loadCalibration(calib) ? 1 : 0; }
+void vis_engine_process_image(void* p, const uint8_t* data, int rows, int cols, size_t step, int channels, int64_t ts) {
+    static_cast<Handle*>(p)->engine.processImage(ImageView(data, rows, cols, step, channels), ts);
+}
+void vis_engine_process_imu(void* p, int64_t ts, const double* acc, const double* gyro) {
+    IMUSample s;
+    s.timestampNs = ts;
+    std::memcpy(s.acceleration, acc, sizeof(s.acceleration));
+    std::memcpy(s.angularVelocity, gyro, sizeof(s.angularVelocity));
+    static_cast<Handle*>(p)->engine.processIMU(s);
+}
+int vis_engine_status(void* p) { return (int)static_cast<Handle*>(p)->engine.getStatus(); }
+/* out: timestamp (as double), position xyz, orientation wxyz; returns 1 if a valid pose exists */
+int vis_engine_pose(void* p, double* out8) {
+    Pose6DoF pose;
+    const bool ok = static_cast<Handle*>(p)->engine.getPose(pose);
+    out8[0] = (double)pose.timestampNs;
+    std::memcpy(out8 + 1, pose.position, 3 * sizeof(double));
+    std::memcpy(out8 + 4, pose.orientation, 4 * sizeof(double));
+    return ok ? 1 : 0;
+}
+int vis_engine_tracked_count(void* p) { return static_cast<Handle*>(p)->engine.getTrackedFeatureCount(); }
+long vis_engine_pose_callbacks(void* p) { return static_cast<Handle*>(p)->poseCalls; }
+long vis_engine_status_callbacks(void* p) { return static_cast<Handle*>(p)->statusCalls; }
+int vis_engine_last_status(void* p) { return static_cast<Handle*>(p)->lastStatus; }
+void vis_engine_reset(void* p) { static_cast<Handle*>(p)->engine.reset(); }
+void vis_engine_shutdown(void* p) { static_cast<Handle*>(p)->engine.shutdown(); }
+const char* vis_engine_frontend_error(void* p) {
+    Handle* h = static_cast<Handle*>(p);
+    h->err = h->engine.getFrontEndError();
+    return h->err.c_str();
+}
+/* feature positions of the last frame (x, y pairs): corners / tracked points / ORB keypoints */
+int vis_engine_points(void* p, float* xy, int cap) {
+    Handle* h = static_cast<Handle*>(p);
+    ISLAMFramework* f = h->engine.framework();
+    std::vector<float> v;
+    if (auto* a = dynamic_cast<OpenVINSAdapter*>(f)) v = a->getCorners();
+    else if (auto* b = dynamic_cast<BasaltAdapter*>(f)) v = b->getCorners();
+    else if (auto* c = dynamic_cast<VINSMonoAdapter*>(f)) v = c->getTrackedPoints();
+    else if (auto* d = dynamic_cast<ORBSLAM3Adapter*>(f))
+        for (const auto& k : d->getKeypoints()) { v.push_back(k.x); v.push_back(k.y); }
+    int n = (int)(v.size() / 2);
+    if (n > cap) n = cap;
+    std::memcpy(xy, v.data(), (size_t)n * 2 * sizeof(float));
+    return n;
+}
+/* selected configuration values, for parser tests: returns 1 if `key` is known */
+int vis_engine_config_value(void* p, const char* key, double* out) {
+    ISLAMFramework* f = static_cast<Handle*>(p)->engine.framework();
+    const std::string k = key;
+    if (auto* a = dynamic_cast<OpenVINSAdapter*>(f)) {
+        const OpenVINSConfig c = a->getConfig();
+        if (k == "numFeatures") *out = c.numFeatures; else if (k == "minPxDist") *out = c.minPxDist;
+        else if (k == "fastThreshold") *out = c.fastThreshold; else if (k == "gridX") *out = c.gridX;
+        else if (k == "gridY") *out = c.gridY; else if (k == "useKLT") *out = c.useKLT;
+        else if (k == "imuInitWindow") *out = c.imuInitWindow; else if (k == "numKltLevels") *out = c.numKltLevels;
+        else return 0;
+        return 1;
+    }
+    if (auto* b = dynamic_cast<BasaltAdapter*>(f)) {
+        const BasaltConfig c = b->getConfig();
+        if (k == "maxFlowPoints") *out = c.maxFlowPoints; else if (k == "flowQualityThreshold") *out = c.flowQualityThreshold;
+        else if (k == "pyramidLevels") *out = c.pyramidLevels; else if (k == "patchSize") *out = c.patchSize;
+        else if (k == "minDistance") *out = c.minDistance; else if (k == "imuInitWindow") *out = c.imuInitWindow;
+        else if (k == "gravity") *out = c.gravity; else if (k == "maxIterations") *out = c.maxIterations;
+        else return 0;
+        return 1;
+    }
+    if (auto* o = dynamic_cast<ORBSLAM3Adapter*>(f)) {
+        const ORBSLAM3Config c = o->getConfig();
+        if (k == "nFeatures") *out = c.nFeatures; else if (k == "scaleFactor") *out = c.scaleFactor;
+        else if (k == "nLevels") *out = c.nLevels; else if (k == "iniThFAST") *out = c.iniThFAST;
+        else if (k == "minThFAST") *out = c.minThFAST; else if (k == "fx") *out = c.fx;
+        else if (k == "imageWidth") *out = c.imageWidth;
+        else return 0;
+        return 1;
+    }
+    if (auto* v = dynamic_cast<VINSMonoAdapter*>(f)) {
+        const VINSMonoConfig c = v->getConfig();
+        if (k == "maxCnt") *out = c.maxCnt; else if (k == "minDist") *out = c.minDist;
+        else if (k == "equalize") *out = c.equalize; else if (k == "imageWidth") *out = c.imageWidth;
+        else if (k == "imageHeight") *out = c.imageHeight;
+        else return 0;
+        return 1;
+    }
+    return 0;
+}
+
+}  // extern "C"

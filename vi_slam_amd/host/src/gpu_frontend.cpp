@@ -1,0 +1,95 @@
+#include "slam/gpu_frontend.hpp"
+#include "common/logging.hpp"
+
+namespace vi_slam {
+
+GpuFrontEnd::~GpuFrontEnd() { release(); }
+
+void GpuFrontEnd::configure(int maxFeatures, int pyramidLevels, int winSize, int orbLevels, int device) {
+    release();
+    cfg_.device = device;
+    cfg_.max_features = maxFeatures > 0 ? maxFeatures : 1;
+    cfg_.pyramid_levels = pyramidLevels < 1 ? 1 : (pyramidLevels > 8 ? 8 : pyramidLevels);
+    cfg_.win_size = winSize;
+    cfg_.orb_levels = orbLevels;
+}
+
+void GpuFrontEnd::release() {
+    if (ctx_) { vfe_destroy(ctx_); ctx_ = nullptr; }
+}
+
+bool GpuFrontEnd::fail(int rc) {
+    error_ = std::string(vfe_status_string(rc)) + ": " + vfe_last_error();
+    LOG_ERROR("GpuFrontEnd", "%s", error_.c_str());
+    return false;
+}
+
+bool GpuFrontEnd::ensure(const ImageView& img) {
+    if (ctx_ && img.cols <= cfg_.max_width && img.rows <= cfg_.max_height) return true;
+    release();
+    cfg_.max_width = img.cols > cfg_.max_width ? img.cols : cfg_.max_width;
+    cfg_.max_height = img.rows > cfg_.max_height ? img.rows : cfg_.max_height;
+    const int rc = vfe_create(&cfg_, &ctx_);
+    if (rc != VFE_OK) { ctx_ = nullptr; return fail(rc); }
+    error_.clear();
+    return true;
+}
+
+bool GpuFrontEnd::detectShiTomasi(const ImageView& img, int maxCorners, double quality, double minDistance, std::vector<float>& xy) {
+    xy.clear();
+    if (maxCorners > cfg_.max_features) { release(); cfg_.max_features = maxCorners; }
+    if (!ensure(img)) return false;
+    xy.resize((size_t)maxCorners * 2);
+    int n = 0;
+    const int rc = vfe_detect_shi_tomasi(ctx_, img.data, img.rows, img.cols, img.step, img.channels(), maxCorners, quality,
+                                         minDistance, xy.data(), &n);
+    if (rc != VFE_OK) { xy.clear(); return fail(rc); }
+    xy.resize((size_t)n * 2);
+    return true;
+}
+
+bool GpuFrontEnd::orbExtract(const ImageView& img, int nFeatures, float scaleFactor, int nLevels, int fastThreshold,
+                             std::vector<vfe_orb_kp>& kps, std::vector<uint8_t>& desc) {
+    kps.clear(); desc.clear();
+    if (nFeatures > cfg_.max_features || nLevels > cfg_.orb_levels) {
+        release();
+        if (nFeatures > cfg_.max_features) cfg_.max_features = nFeatures;
+        if (nLevels > cfg_.orb_levels) cfg_.orb_levels = nLevels;
+    }
+    if (!ensure(img)) return false;
+    const int cap = 2 * nFeatures + 256;
+    kps.resize(cap); desc.resize((size_t)cap * 32);
+    int n = 0;
+    const int rc = vfe_orb_extract(ctx_, img.data, img.rows, img.cols, img.step, img.channels(), nFeatures, scaleFactor,
+                                   nLevels, fastThreshold, kps.data(), desc.data(), cap, &n);
+    if (rc != VFE_OK) { kps.clear(); desc.clear(); return fail(rc); }
+    kps.resize(n); desc.resize((size_t)n * 32);
+    return true;
+}
+
+bool GpuFrontEnd::processFrame(const ImageView& img, int64_t ts, int maxCorners, double quality, double minDistance,
+                               vfe_frame_stats& st) {
+    if (maxCorners > cfg_.max_features) { release(); cfg_.max_features = maxCorners; }
+    if (!ensure(img)) return false;
+    const int rc = vfe_process_frame(ctx_, img.data, img.rows, img.cols, img.step, img.channels(), ts, maxCorners, quality,
+                                     minDistance, &st);
+    if (rc != VFE_OK) return fail(rc);
+    return true;
+}
+
+bool GpuFrontEnd::points(std::vector<float>& xy) {
+    xy.clear();
+    if (!ctx_) return true;
+    xy.resize((size_t)cfg_.max_features * 2);
+    int n = 0;
+    const int rc = vfe_get_points(ctx_, xy.data(), cfg_.max_features, &n);
+    if (rc != VFE_OK) { xy.clear(); return fail(rc); }
+    xy.resize((size_t)n * 2);
+    return true;
+}
+
+void GpuFrontEnd::reset() {
+    if (ctx_) (void)vfe_reset(ctx_);
+}
+
+}  // namespace vi_slam
