@@ -193,6 +193,217 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int tiles_x, unsigne
     }
 }
 
+/* ---- register-marching eigenvalue kernel ------------------------------------------------------
+ * One wavefront owns a strip of 64 lanes x 4 columns and walks down a band of rows.  Each lane
+ * keeps the last three rows of everything it needs in registers (image bytes, horizontal sums of
+ * the gradient products, eigenvalues, horizontal eigenvalue maxima); values of the neighbouring
+ * columns come from the adjacent lanes by cross-lane shuffles.  No LDS tiles, no barriers; one
+ * coalesced dword load per lane per image row.  Lanes 0,1 and 62,63 are halo: 240 output columns
+ * per strip.  The arithmetic (operation order, roundings, reflect-101 of the product planes) is
+ * that of the tiled kernel above and of the CPU checker, so results stay bit-exact.
+ * Candidates are staged per wave in LDS and flushed with one reservation atomic per 192+ keys. */
+#define EV_OUT 240
+#define EV_STAGE 256
+
+__device__ static inline float shl1(float v) { return __shfl_down(v, 1); } /* value of lane + 1 */
+__device__ static inline float shr1(float v) { return __shfl_up(v, 1); }   /* value of lane - 1 */
+
+template <bool WRITE_MAP, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_gftt_eig2(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
+                                                   float* __restrict__ eigmap, u32* __restrict__ frame_max,
+                                                   u32* __restrict__ cand_count, u64* __restrict__ cand, u32 seg_cap,
+                                                   double quality) {
+    __shared__ u64 s_stage[4][EV_STAGE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned wave = blockIdx.x * 4u + wv, nwaves = gridDim.x * 4u;
+    const int W = img.w, H = img.h;
+    const double scale = 1.0 / ((1 << 2) * 3 * 255.0);
+    const float k_o = (float)scale, k_c = (float)(2.0 * scale);
+    u64* stage = s_stage[wv];
+    const u64 lt_mask = (1ull << lane) - 1ull;
+
+    for (unsigned work = wave; work < total_work; work += nwaves) {
+        const int b = work % img.batch, t = work / img.batch;
+        const int sxi = t % strips_x, byi = t / strips_x;
+        const int X0 = sxi * EV_OUT + 4 * (lane - 2); /* image column of this lane's pixel 0 */
+        const int y0 = byi * band_h, y1 = min(y0 + band_h, H);
+        const uint8_t* ip = img.frame(b);
+        const bool out_lane = lane >= 2 && lane < 62;
+        u32 seen = 0;
+        float prune = 0.f, wmax = 0.f;
+        if (!WRITE_MAP) {
+            seen = __hip_atomic_load(&frame_max[b * GF_CSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wmax = __uint_as_float(seen);
+            prune = (float)((double)wmax * quality);
+        }
+        int nbuf = 0;
+        const int seg = t % GF_NSEG;
+        u64* gdst = cand + ((size_t)b * GF_NSEG + seg) * seg_cap;
+        u32* gcnt = cand_count + (size_t)(b * GF_NSEG + seg) * GF_CSTRIDE;
+        /* column flags: gradient sign flips where the product plane is a reflection */
+        bool xin[4], xflip[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int x = X0 + k; xin[k] = x >= 0 && x < W; xflip[k] = (x == -1 || x == W); }
+
+        u32 rA = 0, rB = 0, rC = 0;           /* image rows yy-2, yy-1, yy: this lane's 4 bytes */
+        /* three-row rings, index 2 = newest row; shifted with plain moves so that every index is
+         * a compile-time constant (runtime-indexed register arrays would spill to scratch) */
+        float hs[3][3][4];                    /* [row][plane][pixel]: rows P-2, P-1, P */
+        float eg[3][4], hm[3][4];             /* rows E-2, E-1, E */
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { eg[i][k] = -1.f; hm[i][k] = -1.f; hs[i][0][k] = hs[i][1][k] = hs[i][2][k] = 0.f; }
+
+        for (int yy = y0 - 3; yy <= y1 + 2; yy++) {
+            /* ---- load image row yy (reflect-101) ---- */
+            rA = rB; rB = rC;
+            {
+                const uint8_t* row = ip + (size_t)reflect101(yy, H) * img.pitch;
+                if (ALIGNED && X0 >= 0 && X0 + 3 < W) rC = *reinterpret_cast<const uint32_t*>(row + X0);
+                else if (X0 + 3 < -4 || X0 > W + 4) rC = 0;
+                else rC = (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
+                          ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
+            }
+            if (yy < y0 - 1) continue;
+            /* ---- gradient products at row P = yy - 1 ---- */
+            const int P = yy - 1;
+            float cv[3][4];
+            {
+                /* 6 columns X0-1 .. X0+4 of the three rows */
+                int c[3][6];
+                const u32 rows[3] = {rA, rB, rC};
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const u32 l = (u32)__shfl_up((int)rows[i], 1), r = (u32)__shfl_down((int)rows[i], 1);
+                    c[i][0] = (int)(l >> 24);
+                    c[i][1] = (int)(rows[i] & 255); c[i][2] = (int)((rows[i] >> 8) & 255);
+                    c[i][3] = (int)((rows[i] >> 16) & 255); c[i][4] = (int)(rows[i] >> 24);
+                    c[i][5] = (int)(r & 255);
+                }
+                const bool yflip = (P == -1 || P == H);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float rx[3], ry[3];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const int a = c[i][k], m = c[i][k + 1], d = c[i][k + 2];
+                        rx[i] = (float)(d - a);
+                        ry[i] = k_c * (float)m + k_o * (float)(a + d);
+                    }
+                    float dx = k_c * rx[1] + k_o * (rx[0] + rx[2]);
+                    float dy = ry[2] - ry[0];
+                    if (xflip[k]) dx = -dx;
+                    if (yflip) dy = -dy;
+                    cv[0][k] = dx * dx; cv[1][k] = dx * dy; cv[2][k] = dy * dy;
+                }
+            }
+            /* ---- horizontal 3-sums at row P ---- */
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const float l = shr1(cv[pl][3]), r = shl1(cv[pl][0]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { hs[0][pl][k] = hs[1][pl][k]; hs[1][pl][k] = hs[2][pl][k]; }
+                hs[2][pl][0] = (l + cv[pl][0]) + cv[pl][1];
+                hs[2][pl][1] = (cv[pl][0] + cv[pl][1]) + cv[pl][2];
+                hs[2][pl][2] = (cv[pl][1] + cv[pl][2]) + cv[pl][3];
+                hs[2][pl][3] = (cv[pl][2] + cv[pl][3]) + r;
+            }
+            if (yy < y0 + 1) continue;
+            /* ---- eigenvalue at row E = yy - 2 (rows E-1, E, E+1 of the sums), and its 3-max ---- */
+            const int E = yy - 2;
+            {
+                const bool yin = E >= 0 && E < H;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    eg[0][k] = eg[1][k]; eg[1][k] = eg[2][k];
+                    hm[0][k] = hm[1][k]; hm[1][k] = hm[2][k];
+                    float e = -1.f;
+                    if (yin && xin[k]) {
+                        const float sxx = (hs[0][0][k] + hs[1][0][k]) + hs[2][0][k];
+                        const float sxy = (hs[0][1][k] + hs[1][1][k]) + hs[2][1][k];
+                        const float syy = (hs[0][2][k] + hs[1][2][k]) + hs[2][2][k];
+                        const float a = sxx * 0.5f, bb = sxy, cc = syy * 0.5f;
+                        const float d = a - cc;
+                        e = (a + cc) - sqrtf(d * d + bb * bb);
+                    }
+                    eg[2][k] = e;
+                }
+                const float l = shr1(eg[2][3]), r = shl1(eg[2][0]);
+                hm[2][0] = fmaxf(fmaxf(l, eg[2][0]), eg[2][1]);
+                hm[2][1] = fmaxf(fmaxf(eg[2][0], eg[2][1]), eg[2][2]);
+                hm[2][2] = fmaxf(fmaxf(eg[2][1], eg[2][2]), eg[2][3]);
+                hm[2][3] = fmaxf(fmaxf(eg[2][2], eg[2][3]), r);
+            }
+            if (yy < y0 + 3) continue;
+            /* ---- output row N = yy - 3: value eg[1], neighbours through hm[0..2] ---- */
+            const int N = yy - 3;
+            if (N >= y1) continue;
+            if (WRITE_MAP) {
+                if (out_lane) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (X0 + k < W) eigmap[((size_t)b * H + N) * W + X0 + k] = eg[1][k];
+                }
+            } else {
+                const bool yok = N >= 1 && N <= H - 2;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float v = eg[1][k];
+                    const int x = X0 + k;
+                    bool isc = false;
+                    if (out_lane && x < W) {
+                        wmax = fmaxf(wmax, v);
+                        if (yok && x >= 1 && x <= W - 2 && v > 0.f && v > prune)
+                            isc = v >= fmaxf(fmaxf(hm[0][k], hm[1][k]), hm[2][k]);
+                    }
+                    const u64 m = __ballot(isc);
+                    if (m) {
+                        const int cnt = __popcll(m);
+                        if (nbuf + cnt > EV_STAGE) { /* flush the staged keys */
+                            u32 base = 0;
+                            if (lane == 0) base = atomicAdd(gcnt, (u32)nbuf);
+                            base = (u32)__shfl((int)base, 0);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            for (int i = lane; i < nbuf; i += 64)
+                                if (base + i < seg_cap) gdst[base + i] = stage[i];
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            nbuf = 0;
+                        }
+                        if (isc) stage[nbuf + __popcll(m & lt_mask)] = ((u64)__float_as_uint(v) << 32) | (u32)(N * W + x);
+                        nbuf += cnt;
+                    }
+                }
+            }
+        }
+        if (!WRITE_MAP) {
+            if (nbuf) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(gcnt, (u32)nbuf);
+                base = (u32)__shfl((int)base, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (int i = lane; i < nbuf; i += 64)
+                    if (base + i < seg_cap) gdst[base + i] = stage[i];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+            if (lane == 0 && wmax > 0.f && __float_as_uint(wmax) > seen) atomicMax(&frame_max[b * GF_CSTRIDE], __float_as_uint(wmax));
+        }
+    }
+}
+
+struct EigGeom { int strips_x, band_h, bands_y; unsigned total; };
+static EigGeom eig_geom(int w, int h, int batch) {
+    EigGeom g;
+    g.strips_x = div_up(w, EV_OUT);
+    g.band_h = 64;
+    while (g.band_h > 16 && (long long)g.strips_x * div_up(h, g.band_h) * batch < 16384) g.band_h /= 2;
+    g.bands_y = div_up(h, g.band_h);
+    g.total = (unsigned)(g.strips_x * g.bands_y * batch);
+    return g;
+}
+
 struct SelParams {
     int W, H, max_corners;
     double quality;
@@ -454,7 +665,10 @@ static GfWs gf_layout(int w, int h, int batch, int max_corners, int seed_cap, do
     L.hdr_off = o; o += align_up((size_t)batch * (1 + GF_NSEG) * GF_CSTRIDE * sizeof(u32), 256);
     L.heads_off = o; o += align_up((size_t)batch * L.gw * L.gh * sizeof(u32), 256);
     L.zero_bytes = o;
-    L.seg_cap = (u32)div_up(div_up(w, GF_TW) * div_up(h, GF_TH), GF_NSEG) * (GF_TW * GF_TH);
+    {   /* a segment receives every GF_NSEG-th (strip, band) item; each can emit one key per pixel */
+        const EigGeom g = eig_geom(w, h, batch);
+        L.seg_cap = (u32)div_up(g.strips_x * g.bands_y, GF_NSEG) * (u32)(EV_OUT * g.band_h);
+    }
     L.cand_off = o; o += align_up((size_t)batch * GF_NSEG * L.seg_cap * sizeof(u64), 256);
     L.nxy_off = o; o += align_up((size_t)batch * L.node_cap * sizeof(u32), 256);
     L.nnext_off = o; o += align_up((size_t)batch * L.node_cap * sizeof(u32), 256);
@@ -496,19 +710,18 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     u32* frame_max = (u32*)(ws + L.hdr_off);
     u32* cand_count = frame_max + (size_t)img->batch * GF_CSTRIDE;
     DImg d = to_dimg(img);
-    const int tiles_x = div_up(d.w, GF_TW), tiles_y = div_up(d.h, GF_TH);
-    VFE_REQUIRE((long long)tiles_x * tiles_y * d.batch < (1ll << 31), "too many tiles");
-    const unsigned total_work = (unsigned)(tiles_x * tiles_y * d.batch);
-    dim3 grid(total_work < GF_MAX_WGS ? total_work : GF_MAX_WGS);
+    const EigGeom g = eig_geom(d.w, d.h, d.batch);
+    const unsigned nblk = (g.total + 3) / 4;
+    dim3 grid(nblk < GF_MAX_WGS ? nblk : GF_MAX_WGS);
     const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
     {
         ProfScope prof(VFE_K_GFTT_EIG, st);
         if (aligned)
-            hipLaunchKernelGGL((k_gftt_eig<false, true>), grid, dim3(256), 0, st, d, tiles_x, total_work, (float*)nullptr, frame_max,
-                               cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality);
+            hipLaunchKernelGGL((k_gftt_eig2<false, true>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+                               (float*)nullptr, frame_max, cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality);
         else
-            hipLaunchKernelGGL((k_gftt_eig<false, false>), grid, dim3(256), 0, st, d, tiles_x, total_work, (float*)nullptr, frame_max,
-                               cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality);
+            hipLaunchKernelGGL((k_gftt_eig2<false, false>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+                               (float*)nullptr, frame_max, cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality);
     }
     VFE_LAUNCH_CHECK();
     SelParams p;
@@ -534,12 +747,12 @@ extern "C" int vfe_dev_min_eigen_map(const vfe_dimg* img, float* eig, void* stre
     VFE_REQUIRE(img->width >= 8 && img->height >= 8, "image must be at least 8x8");
     VFE_REQUIRE(eig, "eig is NULL");
     DImg d = to_dimg(img);
-    const int tiles_x = div_up(d.w, GF_TW), tiles_y = div_up(d.h, GF_TH);
-    const unsigned total_work = (unsigned)(tiles_x * tiles_y * d.batch);
-    dim3 grid(total_work < GF_MAX_WGS ? total_work : GF_MAX_WGS);
+    const EigGeom g = eig_geom(d.w, d.h, d.batch);
+    const unsigned nblk = (g.total + 3) / 4;
+    dim3 grid(nblk < GF_MAX_WGS ? nblk : GF_MAX_WGS);
     ProfScope prof(VFE_K_MISC, (hipStream_t)stream);
-    hipLaunchKernelGGL((k_gftt_eig<true, false>), grid, dim3(256), 0, (hipStream_t)stream, d, tiles_x, total_work, eig, (u32*)nullptr,
-                       (u32*)nullptr, (u64*)nullptr, 0u, 0.0);
+    hipLaunchKernelGGL((k_gftt_eig2<true, false>), grid, dim3(256), 0, (hipStream_t)stream, d, g.strips_x, g.band_h, g.bands_y,
+                       g.total, eig, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, 0u, 0.0);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
