@@ -1,0 +1,34 @@
+/* Shared between the generic and the 21x21 Lucas-Kanade kernels. */
+#pragma once
+#include "vfe_common.h"
+
+#define KLT_MAX_LEVELS 8
+
+struct KltParams {
+    DImg prev[KLT_MAX_LEVELS], next[KLT_MAX_LEVELS];
+    int nlevels;
+    const float* prev_pts;
+    const int* n_pts;
+    int cap;
+    float* next_pts;
+    uint8_t* status;
+    float* err;
+    int win, max_iter;
+    double epsilon; /* squared */
+    double min_eig_thr;
+    int use_initial;
+    unsigned total_work;
+};
+
+__device__ static inline int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+
+/* 14-bit integer bilinear weights, rounded as cv::calcOpticalFlowPyrLK does (cvRound, last weight by difference) */
+__device__ static inline void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+    w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << 14));
+    w01 = __float2int_rn(a * (1.f - b) * (float)(1 << 14));
+    w10 = __float2int_rn((1.f - a) * b * (float)(1 << 14));
+    w11 = (1 << 14) - w00 - w01 - w10;
+}
+
+/* enqueue the 21x21 kernel for p.total_work (frame, point) items */
+void klt21_launch(const KltParams& p, hipStream_t stream);
