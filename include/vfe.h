@@ -50,13 +50,24 @@ int vfe_device_count(int* count);
 /* ------------------------------------------------------------------------------------------
  * Batched device-resident images: `batch` frames of width x height bytes; frame b starts at
  * data + b*frame_stride, row y at + y*pitch.
+ *
+ * `border` > 0 promises that `border` pixels on every side of every frame are allocated (rows
+ * -border .. height+border-1, columns -border .. width+border-1 relative to `data`) and hold the
+ * BORDER_REFLECT_101 extension of the frame, the layout cv::buildOpticalFlowPyramid gives its
+ * levels.  vfe_dev_pyr_down / vfe_dev_build_pyramid fill the border of every level they write;
+ * for images the caller fills (level 0) leave it 0 unless the caller has written the extension.
+ * The tracker reads windows that overhang the frame straight from the border when it is at
+ * least VFE_LK_BORDER wide, and falls back to per-pixel reflection otherwise: results are
+ * identical, padded levels are faster.
  * ---------------------------------------------------------------------------------------- */
+#define VFE_LK_BORDER 32
 typedef struct vfe_dimg {
     uint8_t* data;
     int width, height;
     int pitch;            /* bytes per row */
     int batch;
     size_t frame_stride;  /* bytes between consecutive frames */
+    int border;           /* reflect-101 padding present around every frame, in pixels (0 = none) */
 } vfe_dimg;
 
 /* One ORB keypoint (mirrors the fields of cv::KeyPoint that ORB fills, plus the integer

@@ -51,6 +51,52 @@ def test_build_pyramid_4_levels(cuda):
         assert np.array_equal(a[0].cpu().numpy(), r)
 
 
+@pytest.mark.parametrize("w,h", [(752, 480), (190, 97), (66, 50)])
+def test_pyramid_levels_carry_reflect101_border(cuda, w, h):
+    """Levels the library writes are surrounded by the reflect-101 extension of the level."""
+    ims = [synth.noise(5, w, h), synth.scene(synth.BASE_SEED, w, h, 0)]
+    lv = capi.build_pyramid(capi.alloc_pyramid(to_dev(ims, cuda), 3))
+    B = capi.LK_BORDER
+    for l in (1, 2):
+        t = lv[l]
+        assert t._vfe_border == B
+        b, lh, lw = t.shape
+        # the padded parent buffer: same storage, origin moved back by the border
+        full = t.as_strided((b, lh + 2 * B, lw + 2 * B), t.stride(), t.storage_offset() - B * t.stride(1) - B)
+        for i in range(b):
+            inner = t[i].cpu().numpy()
+            assert np.array_equal(full[i].cpu().numpy(), np.pad(inner, B, mode="reflect")), f"level {l} frame {i}"
+
+
+@pytest.mark.parametrize("padded", [True, False])
+def test_klt_border_points_padded_and_unpadded(cuda, padded):
+    """Points whose windows overhang every side of the image, at every level: identical results with
+    bordered levels (direct reads) and plain levels (reflected reads), both equal to the oracle."""
+    import torch
+    w, h, levels = 400, 300, 4
+    prev = synth.scene(synth.BASE_SEED + 7, w, h, 0)
+    nxt = synth.scene(synth.BASE_SEED + 7, w, h, 1)
+    xs = [0.0, 3.3, 9.75, 14.5, w / 2 + 0.5, w - 15.25, w - 9.5, w - 3.0, w - 1.0]
+    ys = [0.0, 2.6, 9.25, 15.0, h / 2 + 0.25, h - 14.75, h - 9.0, h - 2.5, h - 1.0]
+    pts = np.array([[x, y] for y in ys for x in xs] + [[-3.0, 20.0], [w + 2.0, 50.0], [100.0, -4.0], [100.0, h + 1.0]], np.float32)
+    pl, nl = capi.alloc_pyramid(to_dev([prev], cuda), levels), capi.alloc_pyramid(to_dev([nxt], cuda), levels)
+    if not padded:
+        for lv in (pl, nl):
+            for l in range(1, levels):
+                b, lh, lw = lv[l].shape
+                lv[l] = capi.alloc_image(b, lh, lw, cuda)
+    capi.build_pyramid(pl)
+    capi.build_pyramid(nl)
+    assert all(getattr(t, "_vfe_border", 0) == (capi.LK_BORDER if padded else 0) for t in pl[1:])
+    P = torch.from_numpy(pts[None]).to(cuda)
+    out, st, err = capi.klt_track(pl, nl, P, torch.tensor([len(pts)], dtype=torch.int32, device=cuda))
+    ro, rs, re = ora.klt_track(prev, nxt, pts, 21, levels - 1)
+    assert np.array_equal(st[0].cpu().numpy(), rs)
+    assert rs.sum() > len(pts) // 2
+    assert np.array_equal(out[0].cpu().numpy().view(np.uint32), ro.view(np.uint32))
+    assert np.array_equal(err[0].cpu().numpy().view(np.uint32), re.view(np.uint32))
+
+
 @pytest.mark.parametrize("w,h", [(752, 480), (130, 70), (64, 16), (65, 33)])
 def test_min_eigen_map_bit_exact(cuda, w, h):
     imgs = [synth.scene(synth.BASE_SEED, w, h, 0), synth.noise(11, w, h)]

@@ -22,7 +22,7 @@ class VfeError(RuntimeError):
 class DImg(C.Structure):
     """struct vfe_dimg"""
     _fields_ = [("data", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("pitch", C.c_int),
-                ("batch", C.c_int), ("frame_stride", C.c_size_t)]
+                ("batch", C.c_int), ("frame_stride", C.c_size_t), ("border", C.c_int)]
 
 
 class OrbKp(C.Structure):
@@ -127,10 +127,12 @@ def check(rc):
 
 
 def dimg(t):
-    """vfe_dimg view of a torch uint8 CUDA tensor [B, H, W] (row stride may exceed W)."""
+    """vfe_dimg view of a torch uint8 CUDA tensor [B, H, W] (row stride may exceed W).  Tensors from
+    alloc_image(..., border=n) carry their reflect-101 border width in `_vfe_border`; views derived
+    from them lose the tag and are described as unpadded, which is always safe."""
     assert t.is_cuda and t.dim() == 3 and t.element_size() == 1 and t.stride(2) == 1
     b, h, w = t.shape
-    return DImg(t.data_ptr(), w, h, t.stride(1), b, max(t.stride(0), t.stride(1) * h))
+    return DImg(t.data_ptr(), w, h, t.stride(1), b, max(t.stride(0), t.stride(1) * h), getattr(t, "_vfe_border", 0))
 
 
 def _stream():
@@ -144,12 +146,19 @@ def _ptr(t):
 
 # ---- thin helpers over the device entry points (torch tensors in, torch tensors out) ----------
 
-def alloc_image(batch, h, w, device="cuda", align=256):
-    """uint8 [B, H, W] view whose rows and frames start on `align`-byte boundaries."""
+LK_BORDER = 32  # VFE_LK_BORDER
+
+
+def alloc_image(batch, h, w, device="cuda", align=256, border=0):
+    """uint8 [B, H, W] view whose rows and frames start on `align`-byte boundaries.  With `border`
+    the view sits inside a buffer with that many spare pixels on every side (the reflect-101 margin
+    pyramid levels carry for the tracker)."""
     import torch
-    pitch = (w + align - 1) // align * align
-    buf = torch.empty((batch, h, pitch), dtype=torch.uint8, device=device)
-    return buf[:, :, :w]
+    pitch = (w + 2 * border + align - 1) // align * align
+    buf = torch.empty((batch, h + 2 * border, pitch), dtype=torch.uint8, device=device)
+    view = buf[:, border:border + h, border:border + w]
+    view._vfe_border = border
+    return view
 
 
 def pyr_down(src, dst=None):
@@ -168,7 +177,7 @@ def alloc_pyramid(img, nlevels):
     lv = [img]
     for _ in range(1, nlevels):
         b, h, w = lv[-1].shape
-        lv.append(alloc_image(b, (h + 1) // 2, (w + 1) // 2, img.device))
+        lv.append(alloc_image(b, (h + 1) // 2, (w + 1) // 2, img.device, border=LK_BORDER))
     return lv
 
 

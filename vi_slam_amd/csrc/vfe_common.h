@@ -52,6 +52,7 @@ struct DImg {
     uint8_t* data;
     int w, h, pitch, batch;
     size_t fstride;
+    int border; /* reflect-101 padding around every frame, in pixels */
     /* optional second level: each frame is cut into sub_n equal windows (sub_gx per row,
      * sub_dx bytes apart horizontally, sub_dy bytes apart vertically) and `batch` counts
      * windows; sub_n = 1 means whole frames */
@@ -68,12 +69,13 @@ struct DImg {
 
 static inline DImg to_dimg(const vfe_dimg* v) {
     DImg d; d.data = v->data; d.w = v->width; d.h = v->height; d.pitch = v->pitch; d.batch = v->batch;
-    d.fstride = v->frame_stride; d.sub_n = 1; d.sub_gx = 1; d.sub_dx = 0; d.sub_dy = 0; return d;
+    d.fstride = v->frame_stride; d.border = v->border; d.sub_n = 1; d.sub_gx = 1; d.sub_dx = 0; d.sub_dy = 0; return d;
 }
 
 static inline int vfe_check_dimg(const vfe_dimg* v, const char* name) {
     if (!v || !v->data || v->width <= 0 || v->height <= 0 || v->batch <= 0 || v->pitch < v->width ||
-        v->frame_stride < (size_t)v->pitch * (size_t)(v->height - 1) + (size_t)v->width) {
+        v->border < 0 || v->border > 1024 || v->pitch < v->width + 2 * v->border ||
+        v->frame_stride < (size_t)v->pitch * (size_t)(v->height - 1 + (v->batch > 1 ? 2 * v->border : 0)) + (size_t)v->width) {
         vfe_set_error("invalid argument: bad image descriptor %s", name);
         return VFE_E_INVALID;
     }

@@ -35,8 +35,12 @@ static int ctx_enter(vfe_ctx* c) {
 }
 
 static vfe_dimg ctx_level(vfe_ctx* c, int slot, int level, int w, int h) {
-    vfe_dimg d; d.data = c->pyr[slot][level]; d.width = w; d.height = h; d.pitch = c->pitch[level]; d.batch = 1;
-    d.frame_stride = (size_t)d.pitch * h;
+    /* levels the library writes itself carry a reflect-101 border for the tracker; level 0 is
+     * uploaded as is */
+    const int bd = level > 0 ? VFE_LK_BORDER : 0;
+    vfe_dimg d; d.width = w; d.height = h; d.pitch = c->pitch[level]; d.batch = 1; d.border = bd;
+    d.data = c->pyr[slot][level] + (size_t)bd * d.pitch + bd;
+    d.frame_stride = (size_t)d.pitch * (h + 2 * bd);
     return d;
 }
 
@@ -61,7 +65,7 @@ static int ctx_upload(vfe_ctx* c, int slot, const uint8_t* data, int rows, int c
     } else {
         const size_t bp = (size_t)c->cfg.max_width * 3;
         VFE_HIP(hipMemcpy2DAsync(c->bgr, bp, data, step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, c->stream));
-        vfe_dimg s; s.data = c->bgr; s.width = cols; s.height = rows; s.pitch = (int)bp; s.batch = 1; s.frame_stride = bp * rows;
+        vfe_dimg s; s.data = c->bgr; s.width = cols; s.height = rows; s.pitch = (int)bp; s.batch = 1; s.frame_stride = bp * rows; s.border = 0;
         vfe_dimg g = ctx_level(c, slot, 0, cols, rows);
         int rc = vfe_dev_bgr2gray(&s, &g, c->stream);
         if (rc) return rc;
@@ -113,8 +117,9 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     int lw = cfg->max_width, lh = cfg->max_height;
     for (int l = 0; l < cfg->pyramid_levels; l++) {
-        c->lw[l] = lw; c->lh[l] = lh; c->pitch[l] = (int)align_up((size_t)lw, 256);
-        for (int s = 0; s < 2; s++) CTX_TRY(hipMalloc((void**)&c->pyr[s][l], (size_t)c->pitch[l] * lh));
+        const int bd = l > 0 ? VFE_LK_BORDER : 0;
+        c->lw[l] = lw; c->lh[l] = lh; c->pitch[l] = (int)align_up((size_t)lw + 2 * bd, 256);
+        for (int s = 0; s < 2; s++) CTX_TRY(hipMalloc((void**)&c->pyr[s][l], (size_t)c->pitch[l] * (lh + 2 * bd)));
         lw = (lw + 1) / 2; lh = (lh + 1) / 2;
     }
     const size_t N = (size_t)cfg->max_features;

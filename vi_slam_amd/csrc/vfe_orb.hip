@@ -479,7 +479,7 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
     vfe_orb_level_sizes(img->width, img->height, scale_factor, nlevels, wh, scales);
     vfe_orb_quotas(nfeatures, scale_factor, nlevels, L.quota);
     for (int l = 0; l < nlevels; l++) {
-        DImg d; d.w = W.w[l]; d.h = W.h[l]; d.pitch = W.pitch[l]; d.batch = batch; d.fstride = (size_t)W.h[l] * W.pitch[l];
+        DImg d; d.border = 0; d.w = W.w[l]; d.h = W.h[l]; d.pitch = W.pitch[l]; d.batch = batch; d.fstride = (size_t)W.h[l] * W.pitch[l];
         d.sub_n = 1; d.sub_gx = 1; d.sub_dx = 0; d.sub_dy = 0;
         d.data = (uint8_t*)(ws + W.blur_off[l]);
         L.blur[l] = d;

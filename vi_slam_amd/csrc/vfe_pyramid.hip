@@ -230,13 +230,67 @@ static int launch_pyr_down(const DImg& s, const DImg& d, hipStream_t st) {
     return VFE_OK;
 }
 
+/* ---- reflect-101 border of a level ----------------------------------------------------------------
+ * Fills the `border` pixels around every frame from the frame's interior, four bytes per thread:
+ * first the left and right margins of the interior rows, then the full-width rows above and below
+ * (corners included; every byte is fetched from the interior, so the two parts are independent). */
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_pad_border(DImg d, unsigned side_items, unsigned per_frame, unsigned total) {
+    const int B = d.border, W = d.w, H = d.h;
+    const int side_g = B / 2;            /* groups of 4 bytes per interior row: 2B / 4 */
+    const int row_g = (W + 2 * B + 3) / 4; /* groups per full-width border row */
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int b = i / per_frame;
+        unsigned t = i - (unsigned)b * per_frame;
+        int x, y;
+        if (t < side_items) {
+            y = (int)(t / (unsigned)side_g);
+            const int k = 4 * (int)(t - (unsigned)y * (unsigned)side_g);
+            x = k < B ? k - B : W + (k - B);
+        } else {
+            t -= side_items;
+            const int ry = (int)(t / (unsigned)row_g);
+            x = 4 * (int)(t - (unsigned)ry * (unsigned)row_g) - B;
+            y = ry < B ? ry - B : H + (ry - B);
+        }
+        uint8_t* fp = d.frame(b);
+        const uint8_t* srow = fp + (ptrdiff_t)reflect101(y, H) * d.pitch;
+        uint32_t v;
+        if (ALIGNED && x >= 0 && x + 3 < W) v = *reinterpret_cast<const uint32_t*>(srow + x);
+        else v = (uint32_t)srow[reflect101(x, W)] | ((uint32_t)srow[reflect101(x + 1, W)] << 8) |
+                 ((uint32_t)srow[reflect101(x + 2, W)] << 16) | ((uint32_t)srow[reflect101(x + 3, W)] << 24);
+        uint8_t* dp = fp + (ptrdiff_t)y * d.pitch + x;
+        if (ALIGNED) *reinterpret_cast<uint32_t*>(dp) = v;
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x + j < W + B) dp[j] = (uint8_t)(v >> (8 * j));
+        }
+    }
+}
+
+static int launch_pad_border(const DImg& d, hipStream_t st) {
+    if (d.border == 0) return VFE_OK;
+    VFE_REQUIRE(d.border % 4 == 0, "border must be a multiple of 4");
+    const unsigned side_items = (unsigned)d.h * (unsigned)(d.border / 2);
+    const unsigned per_frame = side_items + (unsigned)(2 * d.border) * (unsigned)((d.w + 2 * d.border + 3) / 4);
+    const unsigned total = per_frame * (unsigned)d.batch;
+    const unsigned nblk = (total + 255u) / 256u;
+    const bool aligned = d.w % 4 == 0 && (uintptr_t)d.data % 4 == 0 && d.pitch % 4 == 0 && d.fstride % 4 == 0;
+    if (aligned) hipLaunchKernelGGL(k_pad_border<true>, dim3(nblk < 8192u ? nblk : 8192u), dim3(256), 0, st, d, side_items, per_frame, total);
+    else hipLaunchKernelGGL(k_pad_border<false>, dim3(nblk < 8192u ? nblk : 8192u), dim3(256), 0, st, d, side_items, per_frame, total);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
 extern "C" int vfe_dev_pyr_down(const vfe_dimg* src, const vfe_dimg* dst, void* stream) {
     int rc;
     if ((rc = vfe_check_dimg(src, "src")) || (rc = vfe_check_dimg(dst, "dst"))) return rc;
     VFE_REQUIRE(dst->width == (src->width + 1) / 2 && dst->height == (src->height + 1) / 2, "dst must be ((w+1)/2, (h+1)/2)");
     VFE_REQUIRE(dst->batch == src->batch, "batch mismatch");
     VFE_REQUIRE(src->batch <= 65535, "batch too large");
-    return launch_pyr_down(to_dimg(src), to_dimg(dst), (hipStream_t)stream);
+    if ((rc = launch_pyr_down(to_dimg(src), to_dimg(dst), (hipStream_t)stream))) return rc;
+    return launch_pad_border(to_dimg(dst), (hipStream_t)stream);
 }
 
 extern "C" int vfe_dev_build_pyramid(const vfe_dimg* levels, int nlevels, void* stream) {
