@@ -1,18 +1,22 @@
-/* Lucas-Kanade tracking with the common 21x21 window, register-resident (cv::calcOpticalFlowPyrLK
- * semantics, same arithmetic as the generic kernel in vfe_klt.hip).
+/* Lucas-Kanade tracking with the common 21x21 window (cv::calcOpticalFlowPyrLK semantics, same
+ * arithmetic as the generic kernel in vfe_klt.hip).
  *
  * One wavefront tracks FOUR points, one per row of 16 lanes.  The 441 window pixels of a point
  * are split over its 16 lanes as two horizontal spans per lane: lane l owns the whole window
- * row l (21 pixels) and, for l < 15, a 7-pixel third of one of the rows 16..20.  A lane keeps its
- * share of the template in registers for the whole level and reads the image rows it needs
- * straight from global memory with unaligned dword loads (the patches are cache resident after
- * the first touch) -- no LDS, no barriers.  All per-point scalar work (positions, weights, the
- * 2x2 solve, convergence tests) is ordinary per-lane arithmetic, replicated over the 16 lanes
- * of the point, so four points share every instruction issue; control flow is uniform within a
- * row of 16 lanes, which is what the row-wise DPP reductions need.
+ * row l (21 pixels) and, for l < 15, a piece of one of the rows 16..20 (columns 0-7, 8-15 or
+ * 16-20).  A lane keeps its share of the template in registers for the whole level.  All
+ * per-point scalar work (positions, weights, the 2x2 solve, convergence tests) is ordinary
+ * per-lane arithmetic, replicated over the 16 lanes of the point, so four points share every
+ * instruction issue; control flow is uniform within a row of 16 lanes, which is what the
+ * row-wise DPP reductions need.
  *
- * The kernel is bound by vector-ALU issue, not by memory, so the arithmetic is arranged for the
- * packed 16-bit and dot-product instructions of gfx950:
+ * Memory: the 16 lanes of a point fetch its 24x24-byte patch with consecutive unaligned dword
+ * loads (a few cache lines per instruction instead of one per lane) and hand it over through a
+ * private 768-byte LDS area, from which every lane reads the rows of its spans.  The areas of
+ * the four points are independent, so the four rows of the wave may diverge freely; within a
+ * wave LDS operations execute in order, only compiler reordering has to be fenced.
+ *
+ * Arithmetic is arranged for the packed 16-bit and dot-product instructions of gfx950:
  *   - two vertically adjacent pixels travel as one dword (lo = upper row, hi = lower row), made from
  *     the loaded dwords with one v_perm each;
  *   - Scharr row sums and differences are packed 16-bit operations on those pairs (all values fit:
@@ -27,6 +31,10 @@
 #include <float.h>
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+#define KLT_NEED_BORDER 24 /* reflect-101 margin a level needs for direct reads of any accepted window */
+#define PATCH_ROW_DW 8     /* LDS row stride in dwords (24 bytes used) */
+#define PATCH_DW (24 * PATCH_ROW_DW + 16) /* per point; the tail staggers the banks of the four areas */
 
 __device__ static inline s16x2 as_s2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
 __device__ static inline unsigned as_u(s16x2 v) { return __builtin_bit_cast(unsigned, v); }
@@ -53,46 +61,61 @@ __device__ static inline float row_sum_to_float(int v) {
     return (float)__builtin_fma((double)hi, 65536.0, (double)lo);
 }
 
-template <int NDW>
-__device__ static inline void load_dwords(const uint8_t* p, unsigned* w) {
-#pragma unroll
-    for (int k = 0; k < NDW; k++) w[k] = ldu32(p + 4 * k);
-}
-template <int NDW>
-__device__ static inline void load_dwords_reflect(const uint8_t* img, int pitch, int W, int H, int y, int x0, unsigned* w) {
-    const uint8_t* row = img + (size_t)reflect101(y, H) * pitch;
-#pragma unroll
-    for (int k = 0; k < NDW; k++) w[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 4 * NDW; k++) w[k >> 2] |= (unsigned)row[reflect101(x0 + k, W)] << (8 * (k & 3));
-}
-
-/* NROWS image rows starting at row y0, NDW dwords each starting at column x0.  Levels that carry a
- * reflect-101 border wide enough for any window the tracker accepts are read directly; otherwise
- * rows are reflected by index and columns only when the span overhangs the image. */
-#define KLT_NEED_BORDER 24
-template <int NROWS, int NDW>
-__device__ static inline void load_rows(const DImg& im, const uint8_t* fp, int x0, int y0, unsigned (&w)[NROWS][NDW]) {
+/* The 16 lanes of a point copy NROWS rows x 24 bytes, starting at image position (x0, y0), into the
+ * point's LDS area.  Levels that carry a reflect-101 border are read directly; otherwise rows are
+ * reflected by index and columns byte by byte where a dword overhangs the image. */
+template <int NROWS>
+__device__ static inline void stage_patch(const DImg& im, const uint8_t* fp, int x0, int y0, int sub, unsigned* area) {
     const bool padded = im.border >= KLT_NEED_BORDER;
-    if (padded || (x0 >= 0 && x0 + 4 * NDW <= im.w)) {
+    const bool cols_in = padded || (x0 >= 0 && x0 + 24 <= im.w);
+    unsigned v[9];
 #pragma unroll
-        for (int i = 0; i < NROWS; i++) {
-            const int y = padded ? y0 + i : reflect101(y0 + i, im.h);
-            load_dwords<NDW>(fp + (ptrdiff_t)y * im.pitch + x0, w[i]);
+    for (int i = 0; i < 9; i++) {
+        const int d = sub + 16 * i, row = d / 6, k = d - 6 * row;
+        v[i] = 0;
+        if (NROWS * 6 >= 16 * (i + 1) || row < NROWS) {
+            const int y = padded ? y0 + row : reflect101(y0 + row, im.h);
+            const uint8_t* src = fp + (ptrdiff_t)y * im.pitch;
+            const int x = x0 + 4 * k;
+            if (cols_in) v[i] = ldu32(src + x);
+            else v[i] = (unsigned)src[reflect101(x, im.w)] | ((unsigned)src[reflect101(x + 1, im.w)] << 8) |
+                        ((unsigned)src[reflect101(x + 2, im.w)] << 16) | ((unsigned)src[reflect101(x + 3, im.w)] << 24);
         }
-    } else {
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* earlier reads of the area stay ahead of these writes */
 #pragma unroll
-        for (int i = 0; i < NROWS; i++) load_dwords_reflect<NDW>(fp, im.pitch, im.w, im.h, y0 + i, x0, w[i]);
+    for (int i = 0; i < 9; i++) {
+        const int d = sub + 16 * i, row = d / 6, k = d - 6 * row;
+        if (NROWS * 6 >= 16 * (i + 1) || row < NROWS) area[row * PATCH_ROW_DW + k] = v[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+/* NROWS consecutive patch rows starting at `row`, NDW dwords each starting at dword `dw` (NDW = 6: the
+ * whole row; NDW = 3: an 8-byte aligned piece) */
+template <int NROWS, int NDW>
+__device__ static inline void read_rows(const unsigned* area, int row, int dw, unsigned (&w)[NROWS][NDW]) {
+#pragma unroll
+    for (int i = 0; i < NROWS; i++) {
+        const unsigned* r = area + (row + i) * PATCH_ROW_DW + dw;
+        if (NDW == 6) {
+            const uint4 a = *reinterpret_cast<const uint4*>(r);
+            const uint2 c = *reinterpret_cast<const uint2*>(r + 4);
+            w[i][0] = a.x; w[i][1] = a.y; w[i][2] = a.z; w[i][3] = a.w; w[i][4] = c.x; w[i][5] = c.y;
+        } else {
+            const uint2 a = *reinterpret_cast<const uint2*>(r);
+            w[i][0] = a.x; w[i][1] = a.y; w[i][2] = r[2];
+        }
     }
 }
 
 /* Template of a span of NPX pixels in one window row.  w[i] holds image rows y-1 .. y+2, bytes
- * x-1 .. x+NPX+1 (x, y = image position of the span's first pixel, integer part).  Outputs: tC =
- * rounding constant minus template intensity in accumulator scale, Tx/Ty = gradients packed in
- * pairs of pixels; the Gram sums are accumulated. */
+ * x-1 .. x+NPX+1 (x, y = image position of the span's first pixel, integer part); only the first
+ * `nvalid` pixels belong to the window (checked for pixels >= 5 only).  Outputs: tC = rounding
+ * constant minus template intensity in accumulator scale, Tx/Ty = gradients packed in pairs of
+ * pixels (zero for pixels outside the window); the Gram sums are accumulated. */
 template <int NPX>
 __device__ static inline void span_template(const unsigned (&w)[4][(NPX + 6) / 4], unsigned W0, unsigned W1,
-                                            bool interior, int x, int y, int IW, int IH,
+                                            bool interior, int x, int y, int IW, int IH, int nvalid,
                                             int* tC, unsigned* Tx, unsigned* Ty, int& a11, int& a12, int& a22) {
     constexpr int NC = NPX + 3;
     unsigned P12[NC];
@@ -126,6 +149,7 @@ __device__ static inline void span_template(const unsigned (&w)[4][(NPX + 6) / 4
         const int ival = dot2(P12[k + 1], W0, dot2(P12[k + 2], W1, 1 << 8)) >> 9;
         ix[k] = dot2(vx[k], W0, dot2(vx[k + 1], W1, 1 << 13)) >> 14;
         iy[k] = dot2(vy[k], W0, dot2(vy[k + 1], W1, 1 << 13)) >> 14;
+        if (NPX == 8 && k >= 5 && k >= nvalid) { ix[k] = 0; iy[k] = 0; }
         tC[k] = (1 << 8) - (ival << 9);
         a11 += ix[k] * ix[k]; a12 += ix[k] * iy[k]; a22 += iy[k] * iy[k];
     }
@@ -137,7 +161,7 @@ __device__ static inline void span_template(const unsigned (&w)[4][(NPX + 6) / 4
 /* Intensity differences of a span against its template.  w[i] holds image rows y, y+1, bytes
  * x .. x+NPX. */
 template <int NPX>
-__device__ static inline void span_diff(const unsigned (&w)[2][(NPX + 4) / 4], unsigned W0, unsigned W1, const int* tC, int* diff) {
+__device__ static inline void span_diff(const unsigned (&w)[2][(NPX + 6) / 4], unsigned W0, unsigned W1, const int* tC, int* diff) {
     unsigned Q[NPX + 1];
 #pragma unroll
     for (int k = 0; k < NPX + 1; k++) Q[k] = pair_bytes(k & 3, w[0][k >> 2], w[1][k >> 2]);
@@ -152,21 +176,16 @@ __device__ static inline void span_mismatch(const int* diff, const unsigned* Tx,
         b1 = dot2(d, Tx[k], b1); b2 = dot2(d, Ty[k], b2);
     }
 }
-template <int NPX>
-__device__ static inline int span_abs(const int* diff) {
-    int es = 0;
-#pragma unroll
-    for (int k = 0; k < NPX; k++) es += abs(diff[k]);
-    return es;
-}
 
 __global__ __launch_bounds__(64) void k_klt21(KltParams p) {
+    __shared__ __align__(16) unsigned s_patch[4][PATCH_DW];
     const int lane = threadIdx.x, sub = lane & 15, q = lane >> 4;
-    /* span A: window row sub, columns 0..20.  span B: a third of one of the rows 16..20; lane 15
-     * has none, shadows lane 14's addresses and is left out of the sums */
+    unsigned* area = s_patch[q];
+    /* span A: window row sub, columns 0..20.  span B: a piece of one of the rows 16..20; lane 15
+     * has none, shadows lane 14 and is left out of the sums */
     const bool hasB = sub < 15;
     const int sb = hasB ? sub : 14;
-    const int rB = 16 + sb / 3, cB = (sb - 3 * (sb / 3)) * 7;
+    const int rB = 16 + sb / 3, pB = sb - 3 * (sb / 3), cB = 8 * pB, nB = pB == 2 ? 5 : 8;
     const int win = 21;
     const float half = 10.f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -211,22 +230,24 @@ __global__ __launch_bounds__(64) void k_klt21(KltParams p) {
             bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
             unsigned W0 = (unsigned)iw00 | ((unsigned)iw10 << 16), W1 = (unsigned)iw01 | ((unsigned)iw11 << 16);
 
-            int tCA[21], tCB[7];
+            int tCA[21], tCB[8];
             unsigned TxA[11], TyA[11], TxB[4], TyB[4];
             int a11 = 0, a12 = 0, a22 = 0;
             {
-                /* gradients are needed at columns ipx .. ipx+21, rows ipy .. ipy+21 */
+                /* patch rows ipy-1 .. ipy+22, columns ipx-1 .. ipx+22; gradients are needed at columns
+                 * ipx .. ipx+21, rows ipy .. ipy+21 */
+                stage_patch<24>(I, ip, ipx - 1, ipy - 1, sub, area);
                 const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < I.w && ipy + win < I.h;
                 int b11 = 0, b12 = 0, b22 = 0;
                 {
                     unsigned w[4][6];
-                    load_rows<4, 6>(I, ip, ipx - 1, ipy - 1 + sub, w);
-                    span_template<21>(w, W0, W1, interior, ipx, ipy + sub, I.w, I.h, tCA, TxA, TyA, a11, a12, a22);
+                    read_rows<4, 6>(area, sub, 0, w);
+                    span_template<21>(w, W0, W1, interior, ipx, ipy + sub, I.w, I.h, 21, tCA, TxA, TyA, a11, a12, a22);
                 }
                 {
                     unsigned w[4][3];
-                    load_rows<4, 3>(I, ip, ipx - 1 + cB, ipy - 1 + rB, w);
-                    span_template<7>(w, W0, W1, interior, ipx + cB, ipy + rB, I.w, I.h, tCB, TxB, TyB, b11, b12, b22);
+                    read_rows<4, 3>(area, rB, cB / 4, w);
+                    span_template<8>(w, W0, W1, interior, ipx + cB, ipy + rB, I.w, I.h, nB, tCB, TxB, TyB, b11, b12, b22);
                 }
                 if (hasB) { a11 += b11; a12 += b12; a22 += b22; }
             }
@@ -256,26 +277,32 @@ __global__ __launch_bounds__(64) void k_klt21(KltParams p) {
                 }
                 bilinear_weights(qx - (float)inx, qy - (float)iny, iw00, iw01, iw10, iw11);
                 W0 = (unsigned)iw00 | ((unsigned)iw10 << 16); W1 = (unsigned)iw01 | ((unsigned)iw11 << 16);
-                int dA[21], dB[7];
+                /* patch rows iny .. iny+21, columns inx .. inx+23 (22 used) */
+                stage_patch<22>(J, jp, inx, iny, sub, area);
+                int dA[21], dB[8];
                 {
                     unsigned w[2][6];
-                    load_rows<2, 6>(J, jp, inx, iny + sub, w);
+                    read_rows<2, 6>(area, sub, 0, w);
                     span_diff<21>(w, W0, W1, tCA, dA);
                 }
                 {
-                    unsigned w[2][2];
-                    load_rows<2, 2>(J, jp, inx + cB, iny + rB, w);
-                    span_diff<7>(w, W0, W1, tCB, dB);
+                    unsigned w[2][3];
+                    read_rows<2, 3>(area, rB, cB / 4, w);
+                    span_diff<8>(w, W0, W1, tCB, dB);
                 }
                 if (err_pass) {
-                    int es = span_abs<21>(dA);
-                    if (hasB) es += span_abs<7>(dB);
+                    int es = 0, eb = 0;
+#pragma unroll
+                    for (int k = 0; k < 21; k++) es += abs(dA[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) eb += (k >= 5 && k >= nB) ? 0 : abs(dB[k]);
+                    if (hasB) es += eb;
                     errv = (float)row_sum(es) * 1.f / (float)(32 * win * win);
                     break;
                 }
                 int b1 = 0, b2 = 0, c1 = 0, c2 = 0;
                 span_mismatch<21>(dA, TxA, TyA, b1, b2);
-                span_mismatch<7>(dB, TxB, TyB, c1, c2);
+                span_mismatch<8>(dB, TxB, TyB, c1, c2);
                 if (hasB) { b1 += c1; b2 += c2; }
                 const float fb1 = row_sum_to_float(b1) * FLT_SCALE, fb2 = row_sum_to_float(b2) * FLT_SCALE;
                 const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
