@@ -2,28 +2,31 @@
  * arithmetic as the generic kernel in vfe_klt.hip).
  *
  * One wavefront tracks FOUR points, one per row of 16 lanes.  The 441 window pixels of a point
- * are split over its 16 lanes as two horizontal spans per lane: lane l owns the whole window
- * row l (21 pixels) and, for l < 15, a piece of one of the rows 16..20 (columns 0-7, 8-15 or
- * 16-20).  A lane keeps its share of the template in registers for the whole level.  All
+ * are split over its 16 lanes in pieces of at most 8 pixels of one window row: lane l owns the
+ * whole window row l (pieces at columns 0, 8 and 16) and, for l < 15, one piece of the rows
+ * 16..20.  A lane keeps the gradients of its pixels in registers for the whole level.  All
  * per-point scalar work (positions, weights, the 2x2 solve, convergence tests) is ordinary
  * per-lane arithmetic, replicated over the 16 lanes of the point, so four points share every
  * instruction issue; control flow is uniform within a row of 16 lanes, which is what the
  * row-wise DPP reductions need.
  *
- * Memory: the 16 lanes of a point fetch its 24x24-byte patch with consecutive unaligned dword
+ * Memory: the lanes of a point fetch a 24-byte wide patch with consecutive unaligned 8-byte
  * loads (a few cache lines per instruction instead of one per lane) and hand it over through a
- * private 768-byte LDS area, from which every lane reads the rows of its spans.  The areas of
+ * private 768-byte LDS area, from which every lane reads the rows of its pieces.  The areas of
  * the four points are independent, so the four rows of the wave may diverge freely; within a
- * wave LDS operations execute in order, only compiler reordering has to be fenced.
+ * wave LDS operations execute in order, only compiler reordering has to be fenced.  The patch of
+ * the next image for the coming pass is requested as soon as its position is known, i.e. before
+ * the template is computed and before the bookkeeping that ends a pass.
  *
  * Arithmetic is arranged for the packed 16-bit and dot-product instructions of gfx950:
  *   - two vertically adjacent pixels travel as one dword (lo = upper row, hi = lower row), made from
  *     the loaded dwords with one v_perm each;
  *   - Scharr row sums and differences are packed 16-bit operations on those pairs (all values fit:
  *     |3a+10b+3c| <= 4080);
- *   - a bilinear tap is two v_dot2_i32_i16 with the weight pairs (w00,w10) and (w01,w11); rounding
- *     constant and template value ride in the accumulator operand;
- *   - the mismatch vector is accumulated with v_dot2 over pairs of pixels.
+ *   - a bilinear tap is two v_dot2_i32_i16 with the weight pairs (w00,w10) and (w01,w11);
+ *   - the mismatch vector sum((J - I) * g) is accumulated as sum(J * g) with v_dot2 over pairs of
+ *     pixels, minus sum(I * g), which is a constant of the level; the template intensities I
+ *     themselves are only needed for the final residual and are recomputed there.
  * Window sums are exact integers: per-lane partial sums fit int32, the 16-lane totals are formed
  * separately for the low and high halves and recombined in double before the single rounding to
  * float that the CPU code performs on its 64-bit sum. */
@@ -45,7 +48,14 @@ __device__ static inline unsigned pair_bytes(int k, unsigned a, unsigned b) {
 }
 /* (lo & 0xffff) | (hi << 16) */
 __device__ static inline unsigned pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
-__device__ static inline int dot2(unsigned a, unsigned w, int c) { return __builtin_amdgcn_sdot2(as_s2(a), as_s2(w), c, false); }
+/* a.lo*w.lo + a.hi*w.hi + c on signed 16-bit halves.  Written as the three-address form: the
+ * compiler's choice, the accumulating two-address form, costs a register copy per use whenever the
+ * addend has to survive. */
+__device__ static inline int dot2(unsigned a, unsigned w, int c) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(w), "v"(c));
+    return d;
+}
 
 /* sum over the row of 16 lanes, result in every lane of the row; the row total must fit int32 */
 __device__ static inline int row_sum(int v) {
@@ -61,62 +71,68 @@ __device__ static inline float row_sum_to_float(int v) {
     return (float)__builtin_fma((double)hi, 65536.0, (double)lo);
 }
 
-/* The 16 lanes of a point copy NROWS rows x 24 bytes, starting at image position (x0, y0), into the
- * point's LDS area.  Levels that carry a reflect-101 border are read directly; otherwise rows are
- * reflected by index and columns byte by byte where a dword overhangs the image. */
+/* Twelve of the 16 lanes of a point request NROWS rows x 24 bytes starting at image position
+ * (x0, y0): lane (pr, pk) = (sub / 3, sub % 3) takes bytes 8*pk .. 8*pk+7 of the rows pr, pr+4, ...
+ * Levels that carry a reflect-101 border are read directly; otherwise rows are reflected by index
+ * and columns byte by byte where the patch overhangs the image. */
+struct PatchLane { int pr, pk; bool on; };
+__device__ static inline uint2 ldu64(const uint8_t* p) { uint2 v; __builtin_memcpy(&v, p, 8); return v; }
 template <int NROWS>
-__device__ static inline void stage_patch(const DImg& im, const uint8_t* fp, int x0, int y0, int sub, unsigned* area) {
+__device__ static inline void fetch_patch(const DImg& im, const uint8_t* fp, int x0, int y0, const PatchLane& P, uint2 (&v)[6]) {
     const bool padded = im.border >= KLT_NEED_BORDER;
     const bool cols_in = padded || (x0 >= 0 && x0 + 24 <= im.w);
-    unsigned v[9];
+    const int x = x0 + 8 * P.pk;
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        const int d = sub + 16 * i, row = d / 6, k = d - 6 * row;
-        v[i] = 0;
-        if (NROWS * 6 >= 16 * (i + 1) || row < NROWS) {
+    for (int i = 0; i < 6; i++) {
+        const int row = 4 * i + P.pr;
+        v[i] = make_uint2(0u, 0u);
+        if (P.on && (4 * i + 4 <= NROWS || row < NROWS)) {
             const int y = padded ? y0 + row : reflect101(y0 + row, im.h);
             const uint8_t* src = fp + (ptrdiff_t)y * im.pitch;
-            const int x = x0 + 4 * k;
-            if (cols_in) v[i] = ldu32(src + x);
-            else v[i] = (unsigned)src[reflect101(x, im.w)] | ((unsigned)src[reflect101(x + 1, im.w)] << 8) |
-                        ((unsigned)src[reflect101(x + 2, im.w)] << 16) | ((unsigned)src[reflect101(x + 3, im.w)] << 24);
+            if (cols_in) v[i] = ldu64(src + x);
+            else {
+                unsigned lo = 0, hi = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    lo |= (unsigned)src[reflect101(x + k, im.w)] << (8 * k);
+                    hi |= (unsigned)src[reflect101(x + 4 + k, im.w)] << (8 * k);
+                }
+                v[i] = make_uint2(lo, hi);
+            }
         }
     }
+}
+/* ... and publish them in the point's LDS area */
+template <int NROWS>
+__device__ static inline void store_patch(const uint2 (&v)[6], const PatchLane& P, unsigned* area) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* earlier reads of the area stay ahead of these writes */
+    uint2* dst = reinterpret_cast<uint2*>(area + P.pr * PATCH_ROW_DW + 2 * P.pk);
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        const int d = sub + 16 * i, row = d / 6, k = d - 6 * row;
-        if (NROWS * 6 >= 16 * (i + 1) || row < NROWS) area[row * PATCH_ROW_DW + k] = v[i];
-    }
+    for (int i = 0; i < 6; i++)
+        if (P.on && (4 * i + 4 <= NROWS || 4 * i + P.pr < NROWS)) dst[i * 4 * PATCH_ROW_DW / 2] = v[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
-/* NROWS consecutive patch rows starting at `row`, NDW dwords each starting at dword `dw` (NDW = 6: the
- * whole row; NDW = 3: an 8-byte aligned piece) */
-template <int NROWS, int NDW>
-__device__ static inline void read_rows(const unsigned* area, int row, int dw, unsigned (&w)[NROWS][NDW]) {
+/* NROWS consecutive patch rows starting at `row`, three dwords each starting at dword `dw` (even) */
+template <int NROWS>
+__device__ static inline void read_piece(const unsigned* area, int row, int dw, unsigned (&w)[NROWS][3]) {
 #pragma unroll
     for (int i = 0; i < NROWS; i++) {
         const unsigned* r = area + (row + i) * PATCH_ROW_DW + dw;
-        if (NDW == 6) {
-            const uint4 a = *reinterpret_cast<const uint4*>(r);
-            const uint2 c = *reinterpret_cast<const uint2*>(r + 4);
-            w[i][0] = a.x; w[i][1] = a.y; w[i][2] = a.z; w[i][3] = a.w; w[i][4] = c.x; w[i][5] = c.y;
-        } else {
-            const uint2 a = *reinterpret_cast<const uint2*>(r);
-            w[i][0] = a.x; w[i][1] = a.y; w[i][2] = r[2];
-        }
+        const uint2 a = *reinterpret_cast<const uint2*>(r);
+        w[i][0] = a.x; w[i][1] = a.y; w[i][2] = r[2];
     }
 }
 
-/* Template of a span of NPX pixels in one window row.  w[i] holds image rows y-1 .. y+2, bytes
- * x-1 .. x+NPX+1 (x, y = image position of the span's first pixel, integer part); only the first
- * `nvalid` pixels belong to the window (checked for pixels >= 5 only).  Outputs: tC = rounding
- * constant minus template intensity in accumulator scale, Tx/Ty = gradients packed in pairs of
- * pixels (zero for pixels outside the window); the Gram sums are accumulated. */
-template <int NPX>
-__device__ static inline void span_template(const unsigned (&w)[4][(NPX + 6) / 4], unsigned W0, unsigned W1,
-                                            bool interior, int x, int y, int IW, int IH, int nvalid,
-                                            int* tC, unsigned* Tx, unsigned* Ty, int& a11, int& a12, int& a22) {
+/* Gradient template of a piece of NPX <= 8 pixels of one window row.  w[i] holds image rows
+ * y-1 .. y+2, bytes x-1 .. x+10 (x, y = image position of the piece's first pixel, integer
+ * part); only the first `nvalid` pixels belong to the window (checked for pixels >= 5 only).
+ * Tx/Ty receive the bilinear-interpolated Scharr gradients packed in pairs of pixels (zero
+ * outside the window); the Gram sums and the sums I*gx, I*gy are accumulated.  MASKED is the
+ * variant for windows that overhang the image. */
+template <int NPX, bool MASKED>
+__device__ static inline void piece_template(const unsigned (&w)[4][3], unsigned W0, unsigned W1,
+                                             bool interior, int x, int y, int IW, int IH, int nvalid,
+                                             unsigned* Tx, unsigned* Ty, int& a11, int& a12, int& a22, int& c1, int& c2) {
     constexpr int NC = NPX + 3;
     unsigned P12[NC];
     s16x2 S[NC], D[NC];
@@ -128,20 +144,17 @@ __device__ static inline void span_template(const unsigned (&w)[4][(NPX + 6) / 4
         S[j] = (as_s2(p01) + as_s2(p23)) * (short)3 + as_s2(P12[j]) * (short)10;
         D[j] = as_s2(p23) - as_s2(p01);
     }
-    /* Scharr at window rows (y, y+1) packed, columns x .. x+NPX */
+    /* Scharr at window rows (y, y+1) packed, columns x .. x+NPX; the derivative image is zero
+     * outside the image (rows masked by halves, columns as a whole) */
+    const unsigned mrow = interior ? 0xFFFFFFFFu
+                                   : ((y >= 0 && y < IH ? 0xFFFFu : 0u) | (y + 1 >= 0 && y + 1 < IH ? 0xFFFF0000u : 0u));
     unsigned vx[NPX + 1], vy[NPX + 1];
 #pragma unroll
     for (int j = 0; j < NPX + 1; j++) {
+        const unsigned m = !MASKED || (unsigned)(x + j) < (unsigned)IW ? mrow : 0u;
         vx[j] = as_u(S[j + 2] - S[j]);
         vy[j] = as_u((D[j] + D[j + 2]) * (short)3 + D[j + 1] * (short)10);
-    }
-    if (!interior) { /* the derivative image is zero outside the image */
-        const unsigned mrow = (y >= 0 && y < IH ? 0xFFFFu : 0u) | (y + 1 >= 0 && y + 1 < IH ? 0xFFFF0000u : 0u);
-#pragma unroll
-        for (int j = 0; j < NPX + 1; j++) {
-            const unsigned m = (x + j >= 0 && x + j < IW) ? mrow : 0u;
-            vx[j] &= m; vy[j] &= m;
-        }
+        if (MASKED) { vx[j] &= m; vy[j] &= m; }
     }
     int ix[NPX + 1], iy[NPX + 1];
 #pragma unroll
@@ -149,43 +162,84 @@ __device__ static inline void span_template(const unsigned (&w)[4][(NPX + 6) / 4
         const int ival = dot2(P12[k + 1], W0, dot2(P12[k + 2], W1, 1 << 8)) >> 9;
         ix[k] = dot2(vx[k], W0, dot2(vx[k + 1], W1, 1 << 13)) >> 14;
         iy[k] = dot2(vy[k], W0, dot2(vy[k + 1], W1, 1 << 13)) >> 14;
-        if (NPX == 8 && k >= 5 && k >= nvalid) { ix[k] = 0; iy[k] = 0; }
-        tC[k] = (1 << 8) - (ival << 9);
+        if (k >= 5 && k >= nvalid) { ix[k] = 0; iy[k] = 0; }
         a11 += ix[k] * ix[k]; a12 += ix[k] * iy[k]; a22 += iy[k] * iy[k];
+        c1 += ival * ix[k]; c2 += ival * iy[k];
     }
     ix[NPX] = 0; iy[NPX] = 0;
 #pragma unroll
     for (int k = 0; k < (NPX + 1) / 2; k++) { Tx[k] = pack16(ix[2 * k], ix[2 * k + 1]); Ty[k] = pack16(iy[2 * k], iy[2 * k + 1]); }
 }
 
-/* Intensity differences of a span against its template.  w[i] holds image rows y, y+1, bytes
- * x .. x+NPX. */
+/* Bilinear-interpolated intensities (times 32) of a piece.  w[i] holds image rows y, y+1, bytes
+ * x .. x+11. */
 template <int NPX>
-__device__ static inline void span_diff(const unsigned (&w)[2][(NPX + 6) / 4], unsigned W0, unsigned W1, const int* tC, int* diff) {
+__device__ static inline void piece_values(const unsigned (&w)[2][3], unsigned W0, unsigned W1, int* val) {
     unsigned Q[NPX + 1];
 #pragma unroll
     for (int k = 0; k < NPX + 1; k++) Q[k] = pair_bytes(k & 3, w[0][k >> 2], w[1][k >> 2]);
 #pragma unroll
-    for (int k = 0; k < NPX; k++) diff[k] = dot2(Q[k], W0, dot2(Q[k + 1], W1, tC[k])) >> 9;
+    for (int k = 0; k < NPX; k++) val[k] = dot2(Q[k], W0, dot2(Q[k + 1], W1, 1 << 8)) >> 9;
 }
 template <int NPX>
-__device__ static inline void span_mismatch(const int* diff, const unsigned* Tx, const unsigned* Ty, int& b1, int& b2) {
+__device__ static inline void piece_mismatch(const int* val, const unsigned* Tx, const unsigned* Ty, int& b1, int& b2) {
 #pragma unroll
     for (int k = 0; k < (NPX + 1) / 2; k++) {
-        const unsigned d = pack16(diff[2 * k], 2 * k + 1 < NPX ? diff[2 * k + 1] : 0);
+        const unsigned d = pack16(val[2 * k], 2 * k + 1 < NPX ? val[2 * k + 1] : 0);
         b1 = dot2(d, Tx[k], b1); b2 = dot2(d, Ty[k], b2);
     }
 }
 
-__global__ __launch_bounds__(64) void k_klt21(KltParams p) {
+/* the four pieces of a lane: window row `sub` at columns 0, 8, 16 (8, 8 and 5 pixels) and the
+ * piece (rB, cB) with nB pixels */
+struct LanePieces { int sub, rB, cB, nB; bool hasB; };
+
+/* One pass over the pieces of the lane, patch of the next image staged in `area`: accumulates
+ * sum(J*gx), sum(J*gy) (rows 16..20 piece separately, since lane 15 has none).  The scheduling
+ * barriers keep the pieces from being interleaved, which would multiply the registers in flight. */
+template <int NPX>
+__device__ static inline void piece_pass(const unsigned* area, int row, int dw, unsigned W0, unsigned W1,
+                                         const unsigned* Tx, const unsigned* Ty, int& b1, int& b2) {
+    unsigned w[2][3];
+    int v[NPX];
+    read_piece<2>(area, row, dw, w);
+    piece_values<NPX>(w, W0, W1, v);
+    piece_mismatch<NPX>(v, Tx, Ty, b1, b2);
+    __builtin_amdgcn_sched_barrier(0);
+}
+/* sum |J - I| over the first nvalid pixels of a piece; both patches staged (22-row layout) */
+template <int NPX>
+__device__ static inline int piece_residual(const unsigned* areaJ, const unsigned* areaI, int row, int dw, int nvalid,
+                                            unsigned W0, unsigned W1, unsigned Wt0, unsigned Wt1) {
+    unsigned w[2][3];
+    int vj[NPX], vi[NPX];
+    read_piece<2>(areaJ, row, dw, w);
+    piece_values<NPX>(w, W0, W1, vj);
+    read_piece<2>(areaI, row, dw, w);
+    piece_values<NPX>(w, Wt0, Wt1, vi);
+    int es = 0;
+#pragma unroll
+    for (int k = 0; k < NPX; k++) es += (k >= 5 && k >= nvalid) ? 0 : abs(vj[k] - vi[k]);
+    __builtin_amdgcn_sched_barrier(0);
+    return es;
+}
+
+/* three waves per SIMD: 168 registers, which the kernel fits but for a handful of spills */
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_klt21(KltParams p) {
     __shared__ __align__(16) unsigned s_patch[4][PATCH_DW];
+    __shared__ __align__(16) unsigned s_patch2[4][PATCH_DW]; /* template patch for the residual pass */
     const int lane = threadIdx.x, sub = lane & 15, q = lane >> 4;
     unsigned* area = s_patch[q];
-    /* span A: window row sub, columns 0..20.  span B: a piece of one of the rows 16..20; lane 15
-     * has none, shadows lane 14 and is left out of the sums */
-    const bool hasB = sub < 15;
-    const int sb = hasB ? sub : 14;
-    const int rB = 16 + sb / 3, pB = sb - 3 * (sb / 3), cB = 8 * pB, nB = pB == 2 ? 5 : 8;
+    unsigned* area2 = s_patch2[q];
+    PatchLane P;
+    P.pr = sub / 3; P.pk = sub - 3 * P.pr; P.on = sub < 12;
+    /* lane 15 has no piece in rows 16..20: it shadows lane 14 and is left out of the sums */
+    LanePieces L;
+    L.sub = sub; L.hasB = sub < 15;
+    {
+        const int sb = L.hasB ? sub : 14, pB = sb - 3 * (sb / 3);
+        L.rB = 16 + sb / 3; L.cB = 8 * pB; L.nB = pB == 2 ? 5 : 8;
+    }
     const int win = 21;
     const float half = 10.f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -228,28 +282,43 @@ __global__ __launch_bounds__(64) void k_klt21(KltParams p) {
             }
             int iw00, iw01, iw10, iw11;
             bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
-            unsigned W0 = (unsigned)iw00 | ((unsigned)iw10 << 16), W1 = (unsigned)iw01 | ((unsigned)iw11 << 16);
+            const unsigned Wt0 = (unsigned)iw00 | ((unsigned)iw10 << 16), Wt1 = (unsigned)iw01 | ((unsigned)iw11 << 16);
 
-            int tCA[21], tCB[8];
+            /* request the template patch (rows ipy-1 .. ipy+22, columns ipx-1 .. ipx+22) and, right
+             * behind it, the patch of the next image for the first pass */
+            uint2 vI[6], vJ[6];
+            fetch_patch<24>(I, ip, ipx - 1, ipy - 1, P, vI);
+            nx -= half; ny -= half;
+            float qx = nx, qy = ny;
+            int inx = (int)floorf(qx), iny = (int)floorf(qy);
+            bool inr = !(inx < -win || inx >= J.w || iny < -win || iny >= J.h);
+            if (inr) fetch_patch<22>(J, jp, inx, iny, P, vJ);
+
             unsigned TxA[11], TyA[11], TxB[4], TyB[4];
-            int a11 = 0, a12 = 0, a22 = 0;
+            int a11 = 0, a12 = 0, a22 = 0, c1 = 0, c2 = 0;
             {
-                /* patch rows ipy-1 .. ipy+22, columns ipx-1 .. ipx+22; gradients are needed at columns
-                 * ipx .. ipx+21, rows ipy .. ipy+21 */
-                stage_patch<24>(I, ip, ipx - 1, ipy - 1, sub, area);
+                store_patch<24>(vI, P, area);
+                /* gradients are needed at columns ipx .. ipx+21, rows ipy .. ipy+21 */
                 const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < I.w && ipy + win < I.h;
-                int b11 = 0, b12 = 0, b22 = 0;
-                {
-                    unsigned w[4][6];
-                    read_rows<4, 6>(area, sub, 0, w);
-                    span_template<21>(w, W0, W1, interior, ipx, ipy + sub, I.w, I.h, 21, tCA, TxA, TyA, a11, a12, a22);
-                }
-                {
-                    unsigned w[4][3];
-                    read_rows<4, 3>(area, rB, cB / 4, w);
-                    span_template<8>(w, W0, W1, interior, ipx + cB, ipy + rB, I.w, I.h, nB, tCB, TxB, TyB, b11, b12, b22);
-                }
-                if (hasB) { a11 += b11; a12 += b12; a22 += b22; }
+                int b11 = 0, b12 = 0, b22 = 0, d1 = 0, d2 = 0;
+                unsigned w[4][3];
+                /* wave-uniform choice: the masked variant only when some point of the wave needs it */
+#define KLT_TEMPLATE_PIECES(MASKED)                                                                                        \
+    read_piece<4>(area, sub, 0, w);                                                                                        \
+    piece_template<8, MASKED>(w, Wt0, Wt1, interior, ipx, ipy + sub, I.w, I.h, 8, TxA, TyA, a11, a12, a22, c1, c2);         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    read_piece<4>(area, sub, 2, w);                                                                                        \
+    piece_template<8, MASKED>(w, Wt0, Wt1, interior, ipx + 8, ipy + sub, I.w, I.h, 8, TxA + 4, TyA + 4, a11, a12, a22, c1, c2); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    read_piece<4>(area, sub, 4, w);                                                                                        \
+    piece_template<5, MASKED>(w, Wt0, Wt1, interior, ipx + 16, ipy + sub, I.w, I.h, 5, TxA + 8, TyA + 8, a11, a12, a22, c1, c2); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    read_piece<4>(area, L.rB, L.cB / 4, w);                                                                                \
+    piece_template<8, MASKED>(w, Wt0, Wt1, interior, ipx + L.cB, ipy + L.rB, I.w, I.h, L.nB, TxB, TyB, b11, b12, b22, d1, d2); \
+    __builtin_amdgcn_sched_barrier(0);
+                if (__builtin_amdgcn_ballot_w64(!interior) != 0) { KLT_TEMPLATE_PIECES(true) } else { KLT_TEMPLATE_PIECES(false) }
+#undef KLT_TEMPLATE_PIECES
+                if (L.hasB) { a11 += b11; a12 += b12; a22 += b22; c1 += d1; c2 += d2; }
             }
             const float A11 = row_sum_to_float(a11) * FLT_SCALE, A12 = row_sum_to_float(a12) * FLT_SCALE,
                         A22 = row_sum_to_float(a22) * FLT_SCALE;
@@ -260,51 +329,37 @@ __global__ __launch_bounds__(64) void k_klt21(KltParams p) {
                 continue;
             }
             D = 1.f / D;
-            nx -= half; ny -= half;
             float pdx = 0.f, pdy = 0.f;
-            for (int j = 0; j <= p.max_iter; j++) {
-                /* j == max_iter is the pass that only evaluates the residual at the final position */
-                float qx = nx, qy = ny;
-                const bool err_pass = (j == p.max_iter);
-                if (err_pass) {
-                    if (!(status && level == 0)) break;
-                    qx = outx - half; qy = outy - half;
-                }
-                const int inx = (int)floorf(qx), iny = (int)floorf(qy);
-                if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) {
+            bool err_pass = false;
+            for (int j = 0;;) {
+                if (!inr) {
                     if (level == 0) status = 0;
                     break;
                 }
                 bilinear_weights(qx - (float)inx, qy - (float)iny, iw00, iw01, iw10, iw11);
-                W0 = (unsigned)iw00 | ((unsigned)iw10 << 16); W1 = (unsigned)iw01 | ((unsigned)iw11 << 16);
-                /* patch rows iny .. iny+21, columns inx .. inx+23 (22 used) */
-                stage_patch<22>(J, jp, inx, iny, sub, area);
-                int dA[21], dB[8];
-                {
-                    unsigned w[2][6];
-                    read_rows<2, 6>(area, sub, 0, w);
-                    span_diff<21>(w, W0, W1, tCA, dA);
-                }
-                {
-                    unsigned w[2][3];
-                    read_rows<2, 3>(area, rB, cB / 4, w);
-                    span_diff<8>(w, W0, W1, tCB, dB);
-                }
+                const unsigned W0 = (unsigned)iw00 | ((unsigned)iw10 << 16), W1 = (unsigned)iw01 | ((unsigned)iw11 << 16);
+                store_patch<22>(vJ, P, area);
                 if (err_pass) {
-                    int es = 0, eb = 0;
-#pragma unroll
-                    for (int k = 0; k < 21; k++) es += abs(dA[k]);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) eb += (k >= 5 && k >= nB) ? 0 : abs(dB[k]);
-                    if (hasB) es += eb;
+                    /* residual: the template intensities are the same interpolation of the previous
+                     * image at the window origin */
+                    uint2 vT[6];
+                    fetch_patch<22>(I, ip, ipx, ipy, P, vT);
+                    store_patch<22>(vT, P, area2);
+                    int es = piece_residual<8>(area, area2, sub, 0, 8, W0, W1, Wt0, Wt1);
+                    es += piece_residual<8>(area, area2, sub, 2, 8, W0, W1, Wt0, Wt1);
+                    es += piece_residual<5>(area, area2, sub, 4, 5, W0, W1, Wt0, Wt1);
+                    const int eb = piece_residual<8>(area, area2, L.rB, L.cB / 4, L.nB, W0, W1, Wt0, Wt1);
+                    if (L.hasB) es += eb;
                     errv = (float)row_sum(es) * 1.f / (float)(32 * win * win);
                     break;
                 }
-                int b1 = 0, b2 = 0, c1 = 0, c2 = 0;
-                span_mismatch<21>(dA, TxA, TyA, b1, b2);
-                span_mismatch<8>(dB, TxB, TyB, c1, c2);
-                if (hasB) { b1 += c1; b2 += c2; }
-                const float fb1 = row_sum_to_float(b1) * FLT_SCALE, fb2 = row_sum_to_float(b2) * FLT_SCALE;
+                int b1 = 0, b2 = 0, e1 = 0, e2 = 0;
+                piece_pass<8>(area, sub, 0, W0, W1, TxA, TyA, b1, b2);
+                piece_pass<8>(area, sub, 2, W0, W1, TxA + 4, TyA + 4, b1, b2);
+                piece_pass<5>(area, sub, 4, W0, W1, TxA + 8, TyA + 8, b1, b2);
+                piece_pass<8>(area, L.rB, L.cB / 4, W0, W1, TxB, TyB, e1, e2);
+                if (L.hasB) { b1 += e1; b2 += e2; }
+                const float fb1 = row_sum_to_float(b1 - c1) * FLT_SCALE, fb2 = row_sum_to_float(b2 - c2) * FLT_SCALE;
                 const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
                 nx += dx; ny += dy;
                 outx = nx + half; outy = ny + half;
@@ -314,7 +369,16 @@ __global__ __launch_bounds__(64) void k_klt21(KltParams p) {
                     done = true;
                 }
                 pdx = dx; pdy = dy;
-                if (done || j == p.max_iter - 1) j = p.max_iter - 1; /* next pass is the residual pass */
+                j++;
+                if (done || j == p.max_iter) {
+                    /* last pass: only the residual at the final position, and only where it is reported */
+                    if (!(status && level == 0)) break;
+                    err_pass = true;
+                    qx = outx - half; qy = outy - half;
+                } else { qx = nx; qy = ny; }
+                inx = (int)floorf(qx); iny = (int)floorf(qy);
+                inr = !(inx < -win || inx >= J.w || iny < -win || iny >= J.h);
+                if (inr) fetch_patch<22>(J, jp, inx, iny, P, vJ);
             }
         }
         if (sub == 0) {
