@@ -1,0 +1,30 @@
+/* Shared between the Shi-Tomasi eigenvalue kernel and the corner selection. */
+#pragma once
+#include "vfe_common.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define GF_MAX_WGS 2048u /* persistent workgroups: 256 CUs x 8 */
+#define GF_CSTRIDE 64    /* u32 stride between counters: one 256-B line each, so atomics on
+                            different frames / segments go to different L2 channels */
+#define GF_NSEG 8        /* candidate lists per frame (spreads the reservation atomics) */
+#define EV_OUT 240       /* output columns per wave strip: 60 lanes x 4 pixels (4 halo lanes) */
+
+/* decomposition of a batch into (strip, band, frame) work items, one per wave */
+struct EigGeom { int strips_x, band_h, bands_y; unsigned total; };
+static inline EigGeom eig_geom(int w, int h, int batch) {
+    EigGeom g;
+    g.strips_x = div_up(w, EV_OUT);
+    g.band_h = 64;
+    while (g.band_h > 16 && (long long)g.strips_x * div_up(h, g.band_h) * batch < 16384) g.band_h /= 2;
+    g.bands_y = div_up(h, g.band_h);
+    g.total = (unsigned)(g.strips_x * g.bands_y * batch);
+    return g;
+}
+
+/* Enqueue the eigenvalue pass.  eigmap != NULL: write the float map only.  Otherwise: frame maxima
+ * (as float bits, stride GF_CSTRIDE) and the candidate keys (score bits << 32 | y*W+x) of the 3x3
+ * local maxima, GF_NSEG lists of seg_cap keys per frame with their counters after the maxima. */
+void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_count, u64* cand, u32 seg_cap,
+                     double quality, hipStream_t st);

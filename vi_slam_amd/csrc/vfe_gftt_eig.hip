@@ -1,0 +1,251 @@
+/* Shi-Tomasi eigenvalue pass (cv::cornerMinEigenVal with blockSize 3, Sobel 3, followed by the
+ * 3x3 local-maximum test of cv::goodFeaturesToTrack), register-marching.
+ *
+ * One wavefront owns a strip of 64 lanes x 4 columns and walks down a band of rows; per image row a
+ * lane issues one coalesced dword load.  Everything else stays in registers as rings of three rows:
+ * the horizontal Sobel row filters (so each image row is converted and filtered once, not once per
+ * row it contributes to), the horizontal sums of the gradient products, the eigenvalues and their
+ * horizontal maxima.  The loop is unrolled three times so that the ring slots are compile-time
+ * constants and rows never have to be moved.  Values of the neighbouring columns come from the
+ * adjacent lanes by cross-lane shuffles; lanes 0, 1, 62, 63 are halo (240 output columns per
+ * strip).  No LDS tiles, no barriers.
+ *
+ * The kernel is bound by vector-ALU issue.  The arithmetic (operation order, roundings, sign of
+ * the gradients where the product plane is a reflection) is that of the CPU code, so results stay
+ * bit-exact: (float)(d - a) is formed as float(d) - float(a), which is the same number.
+ *
+ * Local maxima above the running quality threshold are staged per wave in LDS and flushed with
+ * one reservation atomic per batch of keys. */
+#include "vfe_gftt.h"
+#include <type_traits>
+
+#define EV_STAGE 256
+
+template <int N> using ic = std::integral_constant<int, N>;
+
+__device__ static inline float lane_up(float v) { return __shfl_up(v, 1); }     /* value of lane - 1 */
+__device__ static inline float lane_down(float v) { return __shfl_down(v, 1); } /* value of lane + 1 */
+
+template <bool WRITE_MAP, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
+                                                  float* __restrict__ eigmap, u32* __restrict__ frame_max,
+                                                  u32* __restrict__ cand_count, u64* __restrict__ cand, u32 seg_cap,
+                                                  double quality) {
+    __shared__ u64 s_stage[4][EV_STAGE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned wave = blockIdx.x * 4u + wv, nwaves = gridDim.x * 4u;
+    const int W = img.w, H = img.h;
+    const double scale = 1.0 / ((1 << 2) * 3 * 255.0);
+    const float k_o = (float)scale, k_c = (float)(2.0 * scale);
+    u64* stage = s_stage[wv];
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    const bool out_lane = lane >= 2 && lane < 62;
+
+    for (unsigned work = wave; work < total_work; work += nwaves) {
+        const int b = work % img.batch, t_item = work / img.batch;
+        const int sxi = t_item % strips_x, byi = t_item / strips_x;
+        const int X0 = sxi * EV_OUT + 4 * (lane - 2); /* image column of this lane's pixel 0 */
+        const int y0 = byi * band_h, y1 = min(y0 + band_h, H);
+        const uint8_t* ip = img.frame(b);
+        u32 seen = 0;
+        float prune = 0.f, wmax = 0.f;
+        if (!WRITE_MAP) {
+            seen = __hip_atomic_load(&frame_max[b * GF_CSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wmax = __uint_as_float(seen);
+            prune = (float)((double)wmax * quality);
+        }
+        int nbuf = 0;
+        const int seg = t_item % GF_NSEG;
+        u64* gdst = cand + ((size_t)b * GF_NSEG + seg) * seg_cap;
+        u32* gcnt = cand_count + (size_t)(b * GF_NSEG + seg) * GF_CSTRIDE;
+        /* column flags.  xflip: the product plane at x = -1 and x = W is the reflection of the plane,
+         * i.e. the horizontal gradient there changes sign.  Only strips that touch the left or
+         * right rim of the image have any lane with a flag set. */
+        const bool edge_strip = sxi == 0 || sxi * EV_OUT + 4 * 62 > W;
+        bool xin[4], xflip[4], cok[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = X0 + k;
+            xin[k] = x >= 0 && x < W; xflip[k] = (x == -1 || x == W);
+            cok[k] = out_lane && x >= 1 && x <= W - 2;
+        }
+        const bool fast_load = ALIGNED && X0 >= 0 && X0 + 3 < W;
+        const bool dead_load = X0 + 3 < -4 || X0 > W + 4;
+
+        /* three-row rings; the slot of the row handled in step t is t mod 3 */
+        float RX[3][4], RY[3][4];   /* Sobel row filters of image rows yy-2, yy-1, yy */
+        float HS[3][3][4];          /* [slot][plane][pixel]: horizontal sums of product rows P-2, P-1, P */
+        float EG[3][4], HM[3][4];   /* eigenvalue rows E-2, E-1, E and their horizontal 3-maxima */
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                RX[i][k] = RY[i][k] = 0.f; EG[i][k] = HM[i][k] = -1.f;
+                HS[i][0][k] = HS[i][1][k] = HS[i][2][k] = 0.f;
+            }
+
+        /* stc = how far the pipeline is filled: 1 row filters only, 2 + products, 3 + eigenvalues,
+         * 4 + output.  Compile-time, so that a ring slot written in a step is written unconditionally
+         * and the slot it replaces is dead. */
+        auto step = [&](auto phc, auto stc, int t) {
+            constexpr int ST = decltype(stc)::value;
+            constexpr int s0 = decltype(phc)::value, s1 = (s0 + 2) % 3, s2 = (s0 + 1) % 3; /* newest, previous, oldest */
+            const int yy = y0 - 3 + t;
+            /* ---- image row yy (reflect-101): bytes of columns X0-1 .. X0+4 as floats, row filters ---- */
+            {
+                const uint8_t* row = ip + (size_t)reflect101(yy, H) * img.pitch;
+                u32 rC;
+                if (fast_load) rC = *reinterpret_cast<const uint32_t*>(row + X0);
+                else if (dead_load) rC = 0;
+                else rC = (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
+                          ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
+                const u32 l = (u32)__shfl_up((int)rC, 1), r = (u32)__shfl_down((int)rC, 1);
+                float f[6];
+                f[0] = (float)(l >> 24);
+                f[1] = (float)(rC & 255u); f[2] = (float)((rC >> 8) & 255u);
+                f[3] = (float)((rC >> 16) & 255u); f[4] = (float)(rC >> 24);
+                f[5] = (float)(r & 255u);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    RX[s0][k] = f[k + 2] - f[k];
+                    RY[s0][k] = k_c * f[k + 1] + k_o * (f[k] + f[k + 2]);
+                }
+            }
+            if constexpr (ST < 2) return;
+            /* ---- gradient products at row P = yy - 1 and their horizontal 3-sums ---- */
+            {
+                const int P = yy - 1;
+                float cv[3][4];
+                const bool yflip = (P == -1 || P == H);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float dx = k_c * RX[s1][k] + k_o * (RX[s2][k] + RX[s0][k]);
+                    float dy = RY[s0][k] - RY[s2][k];
+                    if (edge_strip && xflip[k]) dx = -dx;
+                    if (yflip) dy = -dy;
+                    cv[0][k] = dx * dx; cv[1][k] = dx * dy; cv[2][k] = dy * dy;
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    const float l = lane_up(cv[pl][3]), r = lane_down(cv[pl][0]);
+                    HS[s0][pl][0] = (l + cv[pl][0]) + cv[pl][1];
+                    HS[s0][pl][1] = (cv[pl][0] + cv[pl][1]) + cv[pl][2];
+                    HS[s0][pl][2] = (cv[pl][1] + cv[pl][2]) + cv[pl][3];
+                    HS[s0][pl][3] = (cv[pl][2] + cv[pl][3]) + r;
+                }
+            }
+            if constexpr (ST < 3) return;
+            /* ---- eigenvalue at row E = yy - 2 (sum rows E-1, E, E+1), and its horizontal 3-max ---- */
+            {
+                const int E = yy - 2;
+                const bool yin = E >= 0 && E < H;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float sxx = (HS[s2][0][k] + HS[s1][0][k]) + HS[s0][0][k];
+                    const float sxy = (HS[s2][1][k] + HS[s1][1][k]) + HS[s0][1][k];
+                    const float syy = (HS[s2][2][k] + HS[s1][2][k]) + HS[s0][2][k];
+                    const float a = sxx * 0.5f, bb = sxy, cc = syy * 0.5f;
+                    const float d = a - cc;
+                    float e = (a + cc) - sqrtf(d * d + bb * bb);
+                    if (!yin || (edge_strip && !xin[k])) e = -1.f;
+                    EG[s0][k] = e;
+                }
+                const float l = lane_up(EG[s0][3]), r = lane_down(EG[s0][0]);
+                HM[s0][0] = fmaxf(fmaxf(l, EG[s0][0]), EG[s0][1]);
+                HM[s0][1] = fmaxf(fmaxf(EG[s0][0], EG[s0][1]), EG[s0][2]);
+                HM[s0][2] = fmaxf(fmaxf(EG[s0][1], EG[s0][2]), EG[s0][3]);
+                HM[s0][3] = fmaxf(fmaxf(EG[s0][2], EG[s0][3]), r);
+            }
+            if constexpr (ST < 4) return;
+            /* ---- output row N = yy - 3: value EG[s1], neighbourhood maxima HM[s2], HM[s1], HM[s0] ---- */
+            const int N = yy - 3;
+            if (WRITE_MAP) {
+                if (out_lane) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (X0 + k < W) eigmap[((size_t)b * H + N) * W + X0 + k] = EG[s1][k];
+                }
+                return;
+            }
+            wmax = fmaxf(wmax, fmaxf(fmaxf(EG[s1][0], EG[s1][1]), fmaxf(EG[s1][2], EG[s1][3])));
+            if (N < 1 || N > H - 2) return;
+            bool isc[4];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float v = EG[s1][k];
+                /* prune >= 0, so v > prune also rejects non-positive responses */
+                isc[k] = cok[k] && v > prune && v >= fmaxf(fmaxf(HM[s2][k], HM[s1][k]), HM[s0][k]);
+                any |= isc[k];
+            }
+            if (__ballot(any) == 0) return;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u64 m = __ballot(isc[k]);
+                if (m) {
+                    const int cnt = __popcll(m);
+                    if (nbuf + cnt > EV_STAGE) { /* flush the staged keys */
+                        u32 base = 0;
+                        if (lane == 0) base = atomicAdd(gcnt, (u32)nbuf);
+                        base = (u32)__shfl((int)base, 0);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        for (int i = lane; i < nbuf; i += 64)
+                            if (base + i < seg_cap) gdst[base + i] = stage[i];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        nbuf = 0;
+                    }
+                    if (isc[k]) stage[nbuf + __popcll(m & lt_mask)] = ((u64)__float_as_uint(EG[s1][k]) << 32) | (u32)(N * W + X0 + k);
+                    nbuf += cnt;
+                }
+            }
+        };
+
+        /* rows y0-3 .. y1+2: six steps fill the pipeline, then every step emits one output row */
+        step(ic<0>{}, ic<1>{}, 0); step(ic<1>{}, ic<1>{}, 1); step(ic<2>{}, ic<2>{}, 2);
+        step(ic<0>{}, ic<2>{}, 3); step(ic<1>{}, ic<3>{}, 4); step(ic<2>{}, ic<3>{}, 5);
+        const int T = 6 + (y1 - y0);
+        int t0 = 6;
+        for (; t0 + 2 < T; t0 += 3) { /* whole triples only: a conditional step would keep the slot it replaces alive */
+            step(ic<0>{}, ic<4>{}, t0);
+            step(ic<1>{}, ic<4>{}, t0 + 1);
+            step(ic<2>{}, ic<4>{}, t0 + 2);
+        }
+        if (t0 < T) step(ic<0>{}, ic<4>{}, t0);
+        if (t0 + 1 < T) step(ic<1>{}, ic<4>{}, t0 + 1);
+        if (!WRITE_MAP) {
+            if (nbuf) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(gcnt, (u32)nbuf);
+                base = (u32)__shfl((int)base, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (int i = lane; i < nbuf; i += 64)
+                    if (base + i < seg_cap) gdst[base + i] = stage[i];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            /* halo lanes hold eigenvalues built from missing neighbours: leave them out of the maximum */
+            if (!out_lane) wmax = 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+            if (lane == 0 && wmax > 0.f && __float_as_uint(wmax) > seen) atomicMax(&frame_max[b * GF_CSTRIDE], __float_as_uint(wmax));
+        }
+    }
+}
+
+void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_count, u64* cand, u32 seg_cap,
+                     double quality, hipStream_t st) {
+    const EigGeom g = eig_geom(d.w, d.h, d.batch);
+    const unsigned nblk = (g.total + 3) / 4;
+    /* one item per wave: items are tens of microseconds long and few per wave, so handing them
+     * out through the dispatcher balances better than persistent waves with a fixed stride */
+    dim3 grid(nblk < (1u << 20) ? nblk : (1u << 20));
+    const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
+    if (eigmap)
+        hipLaunchKernelGGL((k_gftt_eig<true, false>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+                           eigmap, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, 0u, 0.0);
+    else if (aligned)
+        hipLaunchKernelGGL((k_gftt_eig<false, true>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+                           (float*)nullptr, frame_max, cand_count, cand, seg_cap, quality);
+    else
+        hipLaunchKernelGGL((k_gftt_eig<false, false>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+                           (float*)nullptr, frame_max, cand_count, cand, seg_cap, quality);
+}
