@@ -6,13 +6,17 @@
  * the horizontal Sobel row filters (so each image row is converted and filtered once, not once per
  * row it contributes to), the horizontal sums of the gradient products, the eigenvalues and their
  * horizontal maxima.  The loop is unrolled three times so that the ring slots are compile-time
- * constants and rows never have to be moved.  Values of the neighbouring columns come from the
- * adjacent lanes by cross-lane shuffles; lanes 0, 1, 62, 63 are halo (240 output columns per
- * strip).  No LDS tiles, no barriers.
+ * constants and rows never have to be moved; the pipeline fill is unrolled too, so that a slot
+ * written in a step is written unconditionally and the slot it replaces is dead.  Values of the
+ * neighbouring columns come from the adjacent lanes by cross-lane shuffles; lanes 0, 1, 62, 63 are
+ * halo (240 output columns per strip).  No LDS tiles, no barriers.
  *
- * The kernel is bound by vector-ALU issue.  The arithmetic (operation order, roundings, sign of
- * the gradients where the product plane is a reflection) is that of the CPU code, so results stay
- * bit-exact: (float)(d - a) is formed as float(d) - float(a), which is the same number.
+ * The kernel is bound by vector-ALU issue, so a lane's four pixels are kept as two float pairs and
+ * the element-wise stages run as packed fp32 operations (two pixels per instruction).  The
+ * arithmetic (operation order, roundings, sign of the gradients where the product plane is a
+ * reflection) is that of the CPU code, so results stay bit-exact: (float)(d - a) is formed as
+ * float(d) - float(a), which is the same number, and the square root is the hardware estimate
+ * corrected to the nearest float by the usual two residual tests.
  *
  * Local maxima above the running quality threshold are staged per wave in LDS and flushed with
  * one reservation atomic per batch of keys. */
@@ -22,9 +26,22 @@
 #define EV_STAGE 256
 
 template <int N> using ic = std::integral_constant<int, N>;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ static inline float lane_up(float v) { return __shfl_up(v, 1); }     /* value of lane - 1 */
 __device__ static inline float lane_down(float v) { return __shfl_down(v, 1); } /* value of lane + 1 */
+
+/* sqrtf, correctly rounded, for x = 0 or x well inside the normal range (the sums of squares formed
+ * here are 0 or > 1e-29): v_sqrt_f32 is within one ulp, the residuals against the two neighbouring
+ * floats decide.  For x = 0 the lower neighbour is a NaN pattern and both tests fail, leaving 0. */
+__device__ static inline float sqrt_rn(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    s = r_dn <= 0.f ? s_dn : s;
+    s = r_up > 0.f ? s_up : s;
+    return s;
+}
 
 template <bool WRITE_MAP, bool ALIGNED>
 __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
@@ -72,66 +89,71 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
         const bool fast_load = ALIGNED && X0 >= 0 && X0 + 3 < W;
         const bool dead_load = X0 + 3 < -4 || X0 > W + 4;
 
-        /* three-row rings; the slot of the row handled in step t is t mod 3 */
-        float RX[3][4], RY[3][4];   /* Sobel row filters of image rows yy-2, yy-1, yy */
-        float HS[3][3][4];          /* [slot][plane][pixel]: horizontal sums of product rows P-2, P-1, P */
-        float EG[3][4], HM[3][4];   /* eigenvalue rows E-2, E-1, E and their horizontal 3-maxima */
+        /* the item body, specialised (wave-uniformly) for strips away from the rim: all loads are plain
+         * dword loads and no column needs a flag */
+        auto item = [&](auto edgec) {
+        constexpr bool EDGE = decltype(edgec)::value;
+        /* three-row rings of pixel pairs (pixels 0,1 and 2,3); the slot of the row handled in step t
+         * is t mod 3 */
+        f2 RX[3][2], RY[3][2];   /* Sobel row filters of image rows yy-2, yy-1, yy */
+        f2 HS[3][3][2];          /* [slot][plane][pair]: horizontal sums of product rows P-2, P-1, P */
+        f2 EG[3][2], HM[3][2];   /* eigenvalue rows E-2, E-1, E and their horizontal 3-maxima */
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                RX[i][k] = RY[i][k] = 0.f; EG[i][k] = HM[i][k] = -1.f;
-                HS[i][0][k] = HS[i][1][k] = HS[i][2][k] = 0.f;
+            for (int p = 0; p < 2; p++) {
+                RX[i][p] = RY[i][p] = f2{0.f, 0.f}; EG[i][p] = HM[i][p] = f2{-1.f, -1.f};
+                HS[i][0][p] = HS[i][1][p] = HS[i][2][p] = f2{0.f, 0.f};
             }
 
         /* stc = how far the pipeline is filled: 1 row filters only, 2 + products, 3 + eigenvalues,
-         * 4 + output.  Compile-time, so that a ring slot written in a step is written unconditionally
-         * and the slot it replaces is dead. */
+         * 4 + output */
         auto step = [&](auto phc, auto stc, int t) {
             constexpr int ST = decltype(stc)::value;
             constexpr int s0 = decltype(phc)::value, s1 = (s0 + 2) % 3, s2 = (s0 + 1) % 3; /* newest, previous, oldest */
             const int yy = y0 - 3 + t;
-            /* ---- image row yy (reflect-101): bytes of columns X0-1 .. X0+4 as floats, row filters ---- */
+            /* ---- image row yy (reflect-101): columns X0-1 .. X0+4 as floats, row filters ---- */
             {
                 const uint8_t* row = ip + (size_t)reflect101(yy, H) * img.pitch;
                 u32 rC;
-                if (fast_load) rC = *reinterpret_cast<const uint32_t*>(row + X0);
+                if ((ALIGNED && !EDGE) || fast_load) rC = *reinterpret_cast<const uint32_t*>(row + X0);
                 else if (dead_load) rC = 0;
                 else rC = (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
                           ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
                 const u32 l = (u32)__shfl_up((int)rC, 1), r = (u32)__shfl_down((int)rC, 1);
-                float f[6];
-                f[0] = (float)(l >> 24);
-                f[1] = (float)(rC & 255u); f[2] = (float)((rC >> 8) & 255u);
-                f[3] = (float)((rC >> 16) & 255u); f[4] = (float)(rC >> 24);
-                f[5] = (float)(r & 255u);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    RX[s0][k] = f[k + 2] - f[k];
-                    RY[s0][k] = k_c * f[k + 1] + k_o * (f[k] + f[k + 2]);
-                }
+                const float fl = (float)(l >> 24), fr = (float)(r & 255u);
+                const float b0 = (float)(rC & 255u), b1 = (float)((rC >> 8) & 255u);
+                const float b2 = (float)((rC >> 16) & 255u), b3 = (float)(rC >> 24);
+                /* pixel k sees columns k-1, k, k+1: pairs of left, centre and right neighbours */
+                const f2 A = {fl, b0}, B = {b0, b1}, C = {b1, b2}, B2 = {b2, b3}, C2 = {b3, fr};
+                RX[s0][0] = C - A; RX[s0][1] = C2 - C;
+                RY[s0][0] = k_c * B + k_o * (A + C);
+                RY[s0][1] = k_c * B2 + k_o * (C + C2);
             }
             if constexpr (ST < 2) return;
             /* ---- gradient products at row P = yy - 1 and their horizontal 3-sums ---- */
             {
                 const int P = yy - 1;
-                float cv[3][4];
                 const bool yflip = (P == -1 || P == H);
+                f2 cv[3][2];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    float dx = k_c * RX[s1][k] + k_o * (RX[s2][k] + RX[s0][k]);
-                    float dy = RY[s0][k] - RY[s2][k];
-                    if (edge_strip && xflip[k]) dx = -dx;
+                for (int p = 0; p < 2; p++) {
+                    f2 dx = k_c * RX[s1][p] + k_o * (RX[s2][p] + RX[s0][p]);
+                    f2 dy = RY[s0][p] - RY[s2][p];
+                    if (EDGE) {
+                        if (xflip[2 * p]) dx.x = -dx.x;
+                        if (xflip[2 * p + 1]) dx.y = -dx.y;
+                    }
                     if (yflip) dy = -dy;
-                    cv[0][k] = dx * dx; cv[1][k] = dx * dy; cv[2][k] = dy * dy;
+                    cv[0][p] = dx * dx; cv[1][p] = dx * dy; cv[2][p] = dy * dy;
                 }
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++) {
-                    const float l = lane_up(cv[pl][3]), r = lane_down(cv[pl][0]);
-                    HS[s0][pl][0] = (l + cv[pl][0]) + cv[pl][1];
-                    HS[s0][pl][1] = (cv[pl][0] + cv[pl][1]) + cv[pl][2];
-                    HS[s0][pl][2] = (cv[pl][1] + cv[pl][2]) + cv[pl][3];
-                    HS[s0][pl][3] = (cv[pl][2] + cv[pl][3]) + r;
+                    const f2 c01 = cv[pl][0], c23 = cv[pl][1];
+                    const float l = lane_up(c23.y), r = lane_down(c01.x);
+                    const f2 Lp = {l, c01.x}, M = {c01.y, c23.x}, Rp = {c23.y, r};
+                    HS[s0][pl][0] = (Lp + c01) + M;  /* (l + c0) + c1, (c0 + c1) + c2 */
+                    HS[s0][pl][1] = (M + c23) + Rp;  /* (c1 + c2) + c3, (c2 + c3) + r */
                 }
             }
             if constexpr (ST < 3) return;
@@ -140,50 +162,57 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
                 const int E = yy - 2;
                 const bool yin = E >= 0 && E < H;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float sxx = (HS[s2][0][k] + HS[s1][0][k]) + HS[s0][0][k];
-                    const float sxy = (HS[s2][1][k] + HS[s1][1][k]) + HS[s0][1][k];
-                    const float syy = (HS[s2][2][k] + HS[s1][2][k]) + HS[s0][2][k];
-                    const float a = sxx * 0.5f, bb = sxy, cc = syy * 0.5f;
-                    const float d = a - cc;
-                    float e = (a + cc) - sqrtf(d * d + bb * bb);
-                    if (!yin || (edge_strip && !xin[k])) e = -1.f;
-                    EG[s0][k] = e;
+                for (int p = 0; p < 2; p++) {
+                    const f2 sxx = (HS[s2][0][p] + HS[s1][0][p]) + HS[s0][0][p];
+                    const f2 sxy = (HS[s2][1][p] + HS[s1][1][p]) + HS[s0][1][p];
+                    const f2 syy = (HS[s2][2][p] + HS[s1][2][p]) + HS[s0][2][p];
+                    const f2 a = sxx * 0.5f, cc = syy * 0.5f;
+                    const f2 d = a - cc;
+                    const f2 q = d * d + sxy * sxy;
+                    const f2 rt = {sqrt_rn(q.x), sqrt_rn(q.y)};
+                    f2 e = (a + cc) - rt;
+                    if (!yin) e = f2{-1.f, -1.f};
+                    if (EDGE) {
+                        if (!xin[2 * p]) e.x = -1.f;
+                        if (!xin[2 * p + 1]) e.y = -1.f;
+                    }
+                    EG[s0][p] = e;
                 }
-                const float l = lane_up(EG[s0][3]), r = lane_down(EG[s0][0]);
-                HM[s0][0] = fmaxf(fmaxf(l, EG[s0][0]), EG[s0][1]);
-                HM[s0][1] = fmaxf(fmaxf(EG[s0][0], EG[s0][1]), EG[s0][2]);
-                HM[s0][2] = fmaxf(fmaxf(EG[s0][1], EG[s0][2]), EG[s0][3]);
-                HM[s0][3] = fmaxf(fmaxf(EG[s0][2], EG[s0][3]), r);
+                const f2 e01 = EG[s0][0], e23 = EG[s0][1];
+                const float l = lane_up(e23.y), r = lane_down(e01.x);
+                HM[s0][0] = f2{fmaxf(fmaxf(l, e01.x), e01.y), fmaxf(fmaxf(e01.x, e01.y), e23.x)};
+                HM[s0][1] = f2{fmaxf(fmaxf(e01.y, e23.x), e23.y), fmaxf(fmaxf(e23.x, e23.y), r)};
             }
             if constexpr (ST < 4) return;
             /* ---- output row N = yy - 3: value EG[s1], neighbourhood maxima HM[s2], HM[s1], HM[s0] ---- */
             const int N = yy - 3;
+            const float v[4] = {EG[s1][0].x, EG[s1][0].y, EG[s1][1].x, EG[s1][1].y};
             if (WRITE_MAP) {
                 if (out_lane) {
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        if (X0 + k < W) eigmap[((size_t)b * H + N) * W + X0 + k] = EG[s1][k];
+                        if (X0 + k < W) eigmap[((size_t)b * H + N) * W + X0 + k] = v[k];
                 }
                 return;
             }
-            wmax = fmaxf(wmax, fmaxf(fmaxf(EG[s1][0], EG[s1][1]), fmaxf(EG[s1][2], EG[s1][3])));
+            wmax = fmaxf(wmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
             if (N < 1 || N > H - 2) return;
+            const float m[4] = {fmaxf(fmaxf(HM[s2][0].x, HM[s1][0].x), HM[s0][0].x), fmaxf(fmaxf(HM[s2][0].y, HM[s1][0].y), HM[s0][0].y),
+                                fmaxf(fmaxf(HM[s2][1].x, HM[s1][1].x), HM[s0][1].x), fmaxf(fmaxf(HM[s2][1].y, HM[s1][1].y), HM[s0][1].y)};
             bool isc[4];
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const float v = EG[s1][k];
                 /* prune >= 0, so v > prune also rejects non-positive responses */
-                isc[k] = cok[k] && v > prune && v >= fmaxf(fmaxf(HM[s2][k], HM[s1][k]), HM[s0][k]);
+                isc[k] = cok[k] && v[k] > prune && v[k] >= m[k];
                 any |= isc[k];
             }
             if (__ballot(any) == 0) return;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const u64 m = __ballot(isc[k]);
-                if (m) {
-                    const int cnt = __popcll(m);
+                const u64 bm = __ballot(isc[k]);
+                if (bm) {
+                    const int cnt = __popcll(bm);
                     if (nbuf + cnt > EV_STAGE) { /* flush the staged keys */
                         u32 base = 0;
                         if (lane == 0) base = atomicAdd(gcnt, (u32)nbuf);
@@ -194,7 +223,7 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         nbuf = 0;
                     }
-                    if (isc[k]) stage[nbuf + __popcll(m & lt_mask)] = ((u64)__float_as_uint(EG[s1][k]) << 32) | (u32)(N * W + X0 + k);
+                    if (isc[k]) stage[nbuf + __popcll(bm & lt_mask)] = ((u64)__float_as_uint(v[k]) << 32) | (u32)(N * W + X0 + k);
                     nbuf += cnt;
                 }
             }
@@ -212,6 +241,9 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
         }
         if (t0 < T) step(ic<0>{}, ic<4>{}, t0);
         if (t0 + 1 < T) step(ic<1>{}, ic<4>{}, t0 + 1);
+        };
+        if (edge_strip) item(std::true_type{}); else item(std::false_type{});
+
         if (!WRITE_MAP) {
             if (nbuf) {
                 u32 base = 0;
