@@ -23,6 +23,8 @@
 
 #define SEL_THREADS 1024
 #define SEL_M 8192
+#define SEED_CELLS 8192 /* LDS grid of tracked points: heads + two node arrays alias the 64 KiB sort buffer */
+#define SEED_NODES 4096
 
 struct SelParams {
     int W, H, max_corners;
@@ -31,7 +33,7 @@ struct SelParams {
     u32 md2i;
     const u32* frame_max;
     const u32* cand_count;
-    const u64* cand;
+    u64* cand;       /* keys blocked by a tracked point are cleared in place */
     u32 seg_cap;     /* keys per candidate segment; GF_NSEG segments per frame */
     u32* heads;      /* [batch][gw*gh], 0 = empty, else node index + 1 */
     u32* node_xy;    /* [batch][node_cap]  x | y << 16 */
@@ -77,12 +79,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     const int b = blockIdx.x, tid = threadIdx.x;
     __shared__ u32 s_segn[GF_NSEG];
     if (tid < GF_NSEG) s_segn[tid] = min(p.cand_count[(b * GF_NSEG + tid) * GF_CSTRIDE], p.seg_cap);
-    const u64* keys = p.cand + (size_t)b * GF_NSEG * p.seg_cap;
+    u64* keys = p.cand + (size_t)b * GF_NSEG * p.seg_cap;
 /* visit every candidate key of this frame */
 #define FOR_EACH_KEY(k)                                              \
     for (int sg_ = 0; sg_ < GF_NSEG; sg_++) {                         \
         const u32 cn_ = s_segn[sg_];                                 \
-        const u64* kp_ = keys + (size_t)sg_ * p.seg_cap;             \
+        u64* kp_ = keys + (size_t)sg_ * p.seg_cap;                   \
         for (u32 i_ = tid; i_ < cn_; i_ += SEL_THREADS) {            \
             const u64 k = kp_[i_];
 #define END_EACH_KEY }}
@@ -97,23 +99,72 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     /* refill budget: tracked points count towards max_corners */
     const int ns = (p.seeds && p.n_seeds) ? max(0, min(p.n_seeds[b], p.seed_cap)) : 0;
     const int limit = max(0, p.max_corners - ns);
-    /* tracked points occupy the grid first */
+    if (limit == 0) { /* nothing to add: the frame keeps its tracked points */
+        if (tid == 0) p.counts[b] = 0;
+        return;
+    }
+    /* Tracked points occupy the min-distance grid first.  A candidate within min_distance of one of
+     * them is rejected whatever its rank, so when the grid of tracked points fits in LDS (it aliases
+     * the sort buffer, which is not in use yet) all candidates are tested against it in parallel
+     * up front and the blocked ones are cleared; the ordered walk below then only has to consider
+     * the survivors and the corners it accepts itself.  Otherwise the tracked points go into the
+     * global grid and are met during the walk. */
+    const int cells = p.gw * p.gh;
+    const bool lds_seeds = p.use_grid && ns > 0 && cells <= SEED_CELLS && ns <= SEED_NODES;
+    u32* g_heads = reinterpret_cast<u32*>(s_keys);       /* [SEED_CELLS] 0 = empty, else node + 1 */
+    u32* g_xy = g_heads + SEED_CELLS;                    /* [SEED_NODES] x | y << 16 */
+    u32* g_next = g_xy + SEED_NODES;                     /* [SEED_NODES] */
     if (p.use_grid && ns > 0) {
         const float* sd = p.seeds + (size_t)b * p.seed_cap * 2;
+        if (lds_seeds) {
+            for (int c = tid; c < cells; c += SEL_THREADS) g_heads[c] = 0;
+            __syncthreads();
+        }
         for (int s = tid; s < ns; s += SEL_THREADS) {
             const int sx = __float2int_rn(sd[2 * s]), sy = __float2int_rn(sd[2 * s + 1]);
             if (sx < 0 || sy < 0 || sx >= p.W || sy >= p.H) continue;
-            st_agent(&node_xy[s], (u32)sx | ((u32)sy << 16));
-            const u32 old = atomicExch(&heads[(sy / p.cell) * p.gw + sx / p.cell], (u32)s + 1);
-            st_agent(&node_next[s], old);
+            const int c = (sy / p.cell) * p.gw + sx / p.cell;
+            if (lds_seeds) {
+                g_xy[s] = (u32)sx | ((u32)sy << 16);
+                g_next[s] = atomicExch(&g_heads[c], (u32)s + 1);
+            } else {
+                st_agent(&node_xy[s], (u32)sx | ((u32)sy << 16));
+                const u32 old = atomicExch(&heads[c], (u32)s + 1);
+                st_agent(&node_next[s], old);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
-    /* how many candidates pass the exact threshold */
+    /* how many candidates pass the exact threshold (and are not blocked by a tracked point) */
     u32 mine = 0;
-    FOR_EACH_KEY(k) mine += (k > lowkey) ? 1u : 0u; END_EACH_KEY
+    if (lds_seeds) {
+        FOR_EACH_KEY(k)
+            if (k > lowkey) {
+                const u32 idx = (u32)k;
+                const int y = (int)(idx / (u32)p.W), x = (int)(idx - (u32)y * (u32)p.W);
+                const int xc = x / p.cell, yc = y / p.cell;
+                const int x1 = max(0, xc - 1), x2 = min(p.gw - 1, xc + 1);
+                const int y1 = max(0, yc - 1), y2 = min(p.gh - 1, yc + 1);
+                bool blocked = false;
+                for (int yy = y1; yy <= y2 && !blocked; yy++)
+                    for (int xx = x1; xx <= x2 && !blocked; xx++) {
+                        u32 n = g_heads[yy * p.gw + xx];
+                        while (n) {
+                            const u32 q = g_xy[n - 1];
+                            const int dx = x - (int)(q & 0xFFFF), dy = y - (int)(q >> 16);
+                            if ((u32)(dx * dx + dy * dy) < p.md2i) { blocked = true; break; }
+                            n = g_next[n - 1];
+                        }
+                    }
+                if (blocked) kp_[i_] = 0ull; else mine++;
+            }
+        END_EACH_KEY
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        FOR_EACH_KEY(k) mine += (k > lowkey) ? 1u : 0u; END_EACH_KEY
+    }
     const u32 total_valid = block_suffix_scan(mine, s_scan) /* value at tid 0 */;
     __shared__ u32 s_total;
     if (tid == 0) s_total = total_valid;
@@ -339,7 +390,7 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     p.W = d.w; p.H = d.h; p.max_corners = max_corners; p.quality = quality;
     p.use_grid = L.use_grid; p.cell = L.cell; p.gw = L.gw; p.gh = L.gh;
     p.md2i = (u32)ceil(min_distance * min_distance);
-    p.frame_max = frame_max; p.cand_count = cand_count; p.cand = (const u64*)(ws + L.cand_off); p.seg_cap = L.seg_cap;
+    p.frame_max = frame_max; p.cand_count = cand_count; p.cand = (u64*)(ws + L.cand_off); p.seg_cap = L.seg_cap;
     p.heads = (u32*)(ws + L.heads_off); p.node_xy = (u32*)(ws + L.nxy_off); p.node_next = (u32*)(ws + L.nnext_off);
     p.node_cap = L.node_cap;
     p.seeds = seeds_xy; p.n_seeds = n_seeds; p.seed_cap = seed_cap;
