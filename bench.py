@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent streams per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic sequences tiled over the batch")
     ap.add_argument("--frames", type=int, default=4, help="resident frames per stream (visited ping-pong)")
+    ap.add_argument("--loss", type=float, default=0.05,
+                    help="fraction of each stream's tracks dropped after every step (models feature loss, so that "
+                         "every frame has corners to refill; the synthetic scene alone loses almost none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -119,12 +122,17 @@ def main():
     del gf
     order = list(range(1, args.frames)) + list(range(args.frames - 2, -1, -1))
     pos = 0
+    keep_den = 1000
+    keep_num = int(round((1.0 - min(max(args.loss, 0.0), 1.0)) * keep_den))
 
     def one_step():
         nonlocal cur, pos
         nxt = cur ^ 1
         pyr[nxt][0] = frames[order[pos % len(order)]]
         fe.step(pyr[cur], pyr[nxt])
+        if keep_num < keep_den:  # drop the newest tracks: n <- floor(n * keep)
+            torch.mul(fe.n_pts, keep_num, out=fe.n_pts)
+            torch.div(fe.n_pts, keep_den, rounding_mode="floor", out=fe.n_pts)
         cur = nxt
         pos += 1
 
@@ -170,7 +178,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32/f32", "data": "synthetic",
             "config": {"workload": "configs[1]: 1920x1080 streams, 1000 Shi-Tomasi corners + 4-level KLT (win 21) + refill, "
-                                   f"{B} independent streams per GPU per step", "streams_per_gpu": B,
+                                   f"{B} independent streams per GPU per step, {args.loss:.0%} of the tracks dropped per step", "streams_per_gpu": B,
+                       "track_loss_per_step": args.loss,
                        "frame_bytes": W * H, "algo_bytes_per_frame": BYTES_PYR + BYTES_KLT + BYTES_DETECT,
                        "parallelism": f"streams sharded over {world} GPU(s), no collective"},
             "frontend_frac_of_hbm_roofline": value / world * (BYTES_PYR + BYTES_KLT + BYTES_DETECT) / (HBM_PEAK_GBS * 1e9),
