@@ -41,7 +41,7 @@ def make_frames(rank, batch, n_distinct, n_frames):
     return [np.stack([seqs[b % n_distinct][t] for b in range(batch)]) for t in range(n_frames)]
 
 
-def cpu_baseline(frames0, budget_s=12.0):
+def cpu_baseline(frames0, loss, budget_s=12.0):
     """Reference-shaped CPU path (one frame at a time, one thread): LK between consecutive
     frames + refill detection, timed on the CPU oracle built -O3 -march=native."""
     from oracle import oracle as ora
@@ -64,6 +64,7 @@ def cpu_baseline(frames0, budget_s=12.0):
         else:
             pts = tracked
         t_used += time.perf_counter() - t0
+        pts = pts[:int(len(pts) * (1.0 - loss))]  # same track-loss model as the GPU leg
         prev = cur
         done += 1
         i += 1
@@ -77,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="independent streams per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="independent streams per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic sequences tiled over the batch")
     ap.add_argument("--frames", type=int, default=4, help="resident frames per stream (visited ping-pong)")
     ap.add_argument("--loss", type=float, default=0.05,
@@ -170,7 +171,19 @@ def main():
                              "algo_GBs": per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None}
         dom = max(kernels, key=lambda k: kernels[k]["share"])
         roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["algo_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dom]["algo_GBs"] / HBM_PEAK_GBS, "traffic": None}
+                "unit": "GB/s", "frac": kernels[dom]["algo_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                "algo_bytes_per_launch": ALGO_BYTES.get(dom, 0) * B}
+        # HBM bytes per launch from the committed counter passes of this same command (tools/profile_round.sh);
+        # only valid for the batch size they were taken at
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tr.get("streams_per_gpu") == B and dom in tr["kernels"]:
+                roof["traffic"] = tr["kernels"][dom]["total_bytes"]
+                roof["traffic_source"] = "profiles/traffic.json (" + tr.get("tag", "") + ")"
+            if dom in tr.get("limiter", {}):
+                roof["limiter"] = tr["limiter"][dom]
+        except (OSError, ValueError, KeyError):
+            pass
         value = B * world * args.steps / elapsed
         out = {
             "metric": "front-end frames/s at 1920x1080, 1000 feats; % of HBM roofline",
@@ -188,7 +201,7 @@ def main():
             "tracks": {"mean_tracked": float(n_tracked.mean()), "mean_points": float(n_pts.mean())},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline([host[t][0] for t in range(args.frames)])
+            out["cpu_baseline"] = cpu_baseline([host[t][0] for t in range(args.frames)], args.loss)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
