@@ -246,7 +246,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const int max_level = p.nlevels - 1;
     const unsigned n_items = (p.total_work + 3u) / 4u;
 
-    for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {
+    /* Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Items are renumbered so
+     * that all points of a frame run on one XCD (frames f, f+8, ... per XCD): the coarse pyramid levels
+     * of a frame, which all its points read, then stay in that one L2 instead of being fetched by
+     * eight.  Any renumbering is correct as long as it is a bijection; the tail that does not fill a
+     * group of 8 frames keeps its order. */
+    const unsigned per_frame = (unsigned)max(1, p.cap / 4);
+    const unsigned grouped = n_items / (8u * per_frame) * (8u * per_frame);
+    for (unsigned wg = blockIdx.x; wg < n_items; wg += gridDim.x) {
+        unsigned item = wg;
+        if (wg < grouped) {
+            const unsigned xcd = wg & 7u, slot = wg >> 3, grp = slot / per_frame, within = slot - grp * per_frame;
+            item = (grp * 8u + xcd) * per_frame + within;
+        }
         const unsigned idx = item * 4u + (unsigned)q;
         if (idx >= p.total_work) continue;
         const int b = (int)(idx / (unsigned)p.cap), pt = (int)(idx - (unsigned)b * (unsigned)p.cap);
