@@ -88,6 +88,12 @@ typedef struct vfe_orb_kp {
  * bgr has 3*width bytes per row. */
 int vfe_dev_bgr2gray(const vfe_dimg* bgr, const vfe_dimg* gray, void* stream);
 
+/* cv::equalizeHist on 8-bit gray frames (`equalize: 1`, reference config/vins_mono.yaml:104; the
+ * reference's VINS placeholder src/slam/adapters/vins_mono_adapter.cpp:19-23 never reads it).  src and
+ * dst may be the same image.  workspace: vfe_equalize_workspace(batch) bytes, 256-byte aligned. */
+size_t vfe_equalize_workspace(int batch);
+int vfe_dev_equalize_hist(const vfe_dimg* src, const vfe_dimg* dst, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- pyramids -------------------------------------------------------------------------- */
 
 /* cv::pyrDown: dst must be ((w+1)/2) x ((h+1)/2), same batch.  The stage the reference's
@@ -265,6 +271,10 @@ int vfe_create(const vfe_config* cfg, vfe_ctx** out);
 void vfe_destroy(vfe_ctx* ctx);
 /* forget the previous frame and all tracks (ISLAMFramework::reset, i_slam_framework.hpp:103) */
 int vfe_reset(vfe_ctx* ctx);
+/* When enabled, every frame handed to the calls below is histogram-equalised (cv::equalizeHist) on
+ * the GPU after upload / BGR conversion and before anything else reads it: `equalize: 1` of
+ * reference config/vins_mono.yaml:104.  Off by default. */
+int vfe_set_equalize(vfe_ctx* ctx, int enable);
 
 /* goodFeaturesToTrack on a host image (channels 1 or 3; 3 = BGR, converted on the GPU). */
 int vfe_detect_shi_tomasi(vfe_ctx* ctx, const uint8_t* data, int rows, int cols, size_t step, int channels,

@@ -43,6 +43,38 @@ def test_ctx_constant_image_yields_nothing(ctx):
     assert len(k) == 0
 
 
+@pytest.mark.parametrize("w,h", [(752, 480), (131, 67), (64, 16)])
+def test_equalize_hist_bit_exact(cuda, w, h):
+    """cv::equalizeHist (vins_mono.yaml `equalize`): low-contrast scene, noise, a constant frame."""
+    import torch
+    imgs = [(synth.scene(synth.BASE_SEED + 30, w, h, 0) // 4 + 60).astype(np.uint8), synth.noise(9, w, h),
+            np.full((h, w), 77, np.uint8)]
+    t = capi.alloc_image(len(imgs), h, w, cuda)
+    t.copy_(torch.from_numpy(np.stack(imgs)).to(cuda))
+    out = capi.equalize_hist(t).cpu().numpy()
+    for i, im in enumerate(imgs):
+        assert np.array_equal(out[i], ora.equalize_hist(im)), f"frame {i}"
+    # in place, unaligned rows
+    u = torch.empty((1, h, w + 3), dtype=torch.uint8, device=cuda)[:, :, 1:w + 1]
+    u.copy_(torch.from_numpy(imgs[0][None]).to(cuda))
+    capi.equalize_hist(u, u)
+    assert np.array_equal(u[0].cpu().numpy(), ora.equalize_hist(imgs[0]))
+
+
+def test_ctx_equalize_flag(ctx):
+    """With the flag set the context detects on the equalised frame, as VINS-Mono's front-end does."""
+    im = (synth.scene(synth.BASE_SEED + 31, 752, 480, 0) // 3 + 40).astype(np.uint8)
+    ctx.set_equalize(True)
+    try:
+        got = ctx.detect_shi_tomasi(im, 150, 0.01, 30)
+    finally:
+        ctx.set_equalize(False)
+    ref, _ = ora.good_features(ora.equalize_hist(im), 150, 0.01, 30)
+    assert len(ref) > 20 and np.array_equal(got, ref)
+    plain, _ = ora.good_features(im, 150, 0.01, 30)
+    assert np.array_equal(ctx.detect_shi_tomasi(im, 150, 0.01, 30), plain)
+
+
 def test_ctx_klt(ctx):
     w, h = 752, 480
     a, b = synth.scene(synth.BASE_SEED + 22, w, h, 0), synth.scene(synth.BASE_SEED + 22, w, h, 1)

@@ -65,12 +65,15 @@ def test_orbslam3_state_machine_on_keypoint_counts(cuda, tmp_path):
 
 
 def test_vins_mono_stream_tracks_and_refills(cuda, tmp_path):
-    """configs[0]: 752x480, 150 Shi-Tomasi corners (min_dist 30) + pyramidal KLT via vins_mono.yaml."""
-    frames = [synth.scene(synth.BASE_SEED + 53, W, H, t) for t in range(4)]
+    """configs[0]: 752x480, 150 Shi-Tomasi corners (min_dist 30) + pyramidal KLT via vins_mono.yaml,
+    which also sets `equalize: 1`: every frame is histogram-equalised before detection and tracking."""
+    raw = [synth.scene(synth.BASE_SEED + 53, W, H, t) for t in range(4)]
+    assert "equalize: 1" in VINS_YAML
+    frames = [ora.equalize_hist(f) for f in raw]
     e = make_engine(tmp_path, eng.VINS_MONO, VINS_YAML)
     ref = None
     for t, f in enumerate(frames):
-        e.process_image(f, 10**9 + t * 10**8)
+        e.process_image(raw[t], 10**9 + t * 10**8)
         if ref is None:
             ref, _ = ora.good_features(f, 150, 0.01, 30)
         else:

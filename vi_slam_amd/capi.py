@@ -89,6 +89,9 @@ SIGNATURES = {
     "vfe_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "vfe_destroy": (None, [_P]),
     "vfe_reset": (C.c_int, [_P]),
+    "vfe_set_equalize": (C.c_int, [_P, C.c_int]),
+    "vfe_equalize_workspace": (C.c_size_t, [C.c_int]),
+    "vfe_dev_equalize_hist": (C.c_int, [_DI, _DI, _P, C.c_size_t, _P]),
     "vfe_detect_shi_tomasi": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_double,
                                         C.c_double, _P, C.POINTER(C.c_int)]),
     "vfe_klt_track": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int,
@@ -377,6 +380,17 @@ def ratio_test(idx, dist, ratio=0.7):
     return good
 
 
+def equalize_hist(img, out=None):
+    """cv::equalizeHist on a [B, H, W] uint8 cuda batch (in place when out is img)."""
+    import torch
+    if out is None:
+        out = alloc_image(img.shape[0], img.shape[1], img.shape[2], img.device)
+    nbytes = lib().vfe_equalize_workspace(img.shape[0])
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+    check(lib().vfe_dev_equalize_hist(C.byref(dimg(img)), C.byref(dimg(out)), _ptr(ws), nbytes, _stream()))
+    return out
+
+
 def fast_grid(img, threshold, grid_x, grid_y, num_features, min_px_dist, seeds=None, n_seeds=None):
     """(pts [B, cap, 2] float32, scores [B, cap] int32, counts [B])."""
     import torch
@@ -421,6 +435,9 @@ class Context:
 
     def reset(self):
         check(lib().vfe_reset(self._h))
+
+    def set_equalize(self, on):
+        check(lib().vfe_set_equalize(self._h, 1 if on else 0))
 
     def detect_shi_tomasi(self, img, max_corners, quality, min_distance):
         a, p, rows, cols, step, ch = self._img(img)

@@ -26,6 +26,7 @@ struct vfe_ctx {
     vfe_orb_kp* orb_kps; uint8_t* orb_desc; int orb_cap;
     void* mws; size_t mws_bytes;        /* growable: match descriptors + workspace */
     int cur, have_prev, w, h;           /* stream state */
+    int equalize; unsigned* eq_hist;    /* optional histogram equalisation of every uploaded frame */
 };
 
 static int ctx_enter(vfe_ctx* c) {
@@ -70,6 +71,11 @@ static int ctx_upload(vfe_ctx* c, int slot, const uint8_t* data, int rows, int c
         int rc = vfe_dev_bgr2gray(&s, &g, c->stream);
         if (rc) return rc;
     }
+    if (c->equalize) {
+        vfe_dimg g = ctx_level(c, slot, 0, cols, rows);
+        int rc = vfe_dev_equalize_hist(&g, &g, c->eq_hist, vfe_equalize_workspace(1), c->stream);
+        if (rc) return rc;
+    }
     return VFE_OK;
 }
 
@@ -80,7 +86,7 @@ extern "C" void vfe_destroy(vfe_ctx* c) {
     for (int s = 0; s < 2; s++)
         for (int l = 0; l < CTX_MAX_LK_LEVELS; l++) (void)hipFree(c->pyr[s][l]);
     void* bufs[] = {c->bgr, c->pts, c->next_pts, c->corners, c->err, c->status, c->n_pts, c->n_tracked, c->counts,
-                    c->ws, c->orb_kps, c->orb_desc, c->mws};
+                    c->ws, c->orb_kps, c->orb_desc, c->mws, c->eq_hist};
     for (void* p : bufs) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -124,6 +130,7 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
     }
     const size_t N = (size_t)cfg->max_features;
     CTX_TRY(hipMalloc((void**)&c->bgr, (size_t)cfg->max_width * 3 * cfg->max_height));
+    CTX_TRY(hipMalloc((void**)&c->eq_hist, vfe_equalize_workspace(1)));
     CTX_TRY(hipMalloc((void**)&c->pts, N * 2 * sizeof(float)));
     CTX_TRY(hipMalloc((void**)&c->next_pts, N * 2 * sizeof(float)));
     CTX_TRY(hipMalloc((void**)&c->corners, N * 2 * sizeof(float)));
@@ -146,6 +153,12 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
     CTX_TRY(hipStreamSynchronize(c->stream));
 #undef CTX_TRY
     *out = c;
+    return VFE_OK;
+}
+
+extern "C" int vfe_set_equalize(vfe_ctx* c, int enable) {
+    VFE_REQUIRE(c, "ctx is NULL");
+    c->equalize = enable ? 1 : 0;
     return VFE_OK;
 }
 

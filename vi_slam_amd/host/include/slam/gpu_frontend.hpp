@@ -18,6 +18,8 @@ public:
     GpuFrontEnd& operator=(const GpuFrontEnd&) = delete;
 
     void configure(int maxFeatures, int pyramidLevels, int winSize, int orbLevels, int device = 0);
+    /* histogram-equalise every frame before it is used (config/vins_mono.yaml:104 `equalize`) */
+    void setEqualize(bool on);
     /* each returns false and records lastError() on failure; never throws */
     bool detectShiTomasi(const ImageView& img, int maxCorners, double quality, double minDistance, std::vector<float>& xy);
     bool orbExtract(const ImageView& img, int nFeatures, float scaleFactor, int nLevels, int fastThreshold,
@@ -33,6 +35,7 @@ private:
     bool fail(int rc);
     vfe_ctx* ctx_ = nullptr;
     vfe_config cfg_{0, 0, 0, 1000, 4, 21, 0};
+    bool equalize_ = false;
     std::string error_;
 };
 

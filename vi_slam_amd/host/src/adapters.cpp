@@ -24,7 +24,10 @@ void VINSMonoAdapter::configKey(const std::string&, const std::string& key, cons
     else if (key == "pyramid_levels") config_.pyramidLevels = std::stoi(value);
 }
 
-void VINSMonoAdapter::configDone() { frontEnd_.configure(std::max(config_.maxCnt, 1), config_.pyramidLevels, 21, 0); }
+void VINSMonoAdapter::configDone() {
+    frontEnd_.configure(std::max(config_.maxCnt, 1), config_.pyramidLevels, 21, 0);
+    frontEnd_.setEqualize(config_.equalize);
+}
 
 int VINSMonoAdapter::feedImage(const ImageView& image, int64_t timestampNs, const std::vector<IMUSample>&) {
     vfe_frame_stats st{0, 0, 0};

@@ -14,6 +14,11 @@ void GpuFrontEnd::configure(int maxFeatures, int pyramidLevels, int winSize, int
     cfg_.orb_levels = orbLevels;
 }
 
+void GpuFrontEnd::setEqualize(bool on) {
+    equalize_ = on;
+    if (ctx_) (void)vfe_set_equalize(ctx_, on ? 1 : 0);
+}
+
 void GpuFrontEnd::release() {
     if (ctx_) { vfe_destroy(ctx_); ctx_ = nullptr; }
 }
@@ -31,6 +36,7 @@ bool GpuFrontEnd::ensure(const ImageView& img) {
     cfg_.max_height = img.rows > cfg_.max_height ? img.rows : cfg_.max_height;
     const int rc = vfe_create(&cfg_, &ctx_);
     if (rc != VFE_OK) { ctx_ = nullptr; return fail(rc); }
+    (void)vfe_set_equalize(ctx_, equalize_ ? 1 : 0);
     error_.clear();
     return true;
 }
