@@ -238,6 +238,16 @@ int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long 
                        int base_index, int* out_idx, int* out_dist,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for a batch of independent (query, train) pairs, e.g. the descriptors of consecutive frames
+ * of `batch` streams as vfe_dev_orb_extract leaves them: set b has nq[b] (nt[b]) descriptors at
+ * query + b*q_cap*32 (train + b*t_cap*32); nq and nt are DEVICE arrays, so extraction and matching can
+ * be queued without a host round trip.  out_idx/out_dist [batch][q_cap][2], train indices 0-based per
+ * set; rows >= nq[b] get the 'absent' record.  good (optional, [batch][q_cap]) receives Lowe's ratio
+ * test d0 < ratio * d1 (`knn_ratio`).  No workspace. */
+int vfe_dev_match_knn2_batch(const uint8_t* query, const int* nq, int q_cap,
+                             const uint8_t* train, const int* nt, int t_cap, int batch,
+                             int* out_idx, int* out_dist, float ratio, uint8_t* good, void* stream);
+
 /* Merge per-shard top-2 lists (as all-gathered from `nshards` ranks, [nshards][nq][2]) into
  * the global top-2 by (dist, idx) -- the order a single scan over the whole map produces. */
 int vfe_dev_merge_knn2(const int* shard_idx, const int* shard_dist, int nshards, int nq,

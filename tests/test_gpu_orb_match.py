@@ -107,6 +107,30 @@ def test_match_knn2_bit_exact(cuda, nq, nt):
     assert np.array_equal(good, ora.ratio_test(ridx, rdist, 0.7))
 
 
+def test_match_knn2_batch_equals_per_pair_calls(cuda):
+    """Batched frame-to-frame matching with device-side set sizes: every pair equals the oracle's knnMatch +
+    ratio test, including an empty train set, an empty query set and ties."""
+    import torch
+    qcap, tcap = 300, 520
+    nq = np.array([300, 1, 0, 257, 64], np.int32)
+    nt = np.array([520, 3, 100, 0, 1], np.int32)
+    B = len(nq)
+    q = np.stack([synth.descriptors(40 + b, qcap) for b in range(B)])
+    t = np.stack([synth.descriptors(80 + b, tcap) for b in range(B)])
+    for i in range(40):
+        t[0, (i * 13) % 520] = synth.flip_bits(i, q[0, i], i % 20)
+    t[0, 9] = t[0, 400]
+    idx, dist, good = capi.match_knn2_batch(torch.from_numpy(q).to(cuda), torch.from_numpy(nq).to(cuda),
+                                            torch.from_numpy(t).to(cuda), torch.from_numpy(nt).to(cuda), 0.7)
+    idx, dist, good = idx.cpu().numpy(), dist.cpu().numpy(), good.cpu().numpy()
+    for b in range(B):
+        if nq[b]:
+            ridx, rdist = ora.match_knn2(q[b, :nq[b]], t[b, :nt[b]])
+            assert np.array_equal(idx[b, :nq[b]], ridx) and np.array_equal(dist[b, :nq[b]], rdist), f"pair {b}"
+            assert np.array_equal(good[b, :nq[b]], ora.ratio_test(ridx, rdist, 0.7))
+        assert (idx[b, nq[b]:] == -1).all() and (dist[b, nq[b]:] == 0x7fffffff).all() and not good[b, nq[b]:].any()
+
+
 def test_match_sharded_merge_equals_single_scan(cuda):
     """cfg5 shape at reduced size: a map split into 8 contiguous shards, per-shard top-2 merged by
     (dist, idx) equals one scan over the whole map; planted near-duplicates are found."""

@@ -68,9 +68,7 @@ def main():
         n0 = orb[0].counts.cpu().numpy(); n1 = orb[1].counts.cpu().numpy()
 
         def f2f():
-            for b in range(B):
-                idx, dist = capi.match_knn2(orb[1].desc[b, :n1[b]], orb[0].desc[b, :n0[b]])
-                capi.ratio_test(idx, dist, 0.7)
+            capi.match_knn2_batch(orb[1].desc, orb[1].counts, orb[0].desc, orb[0].counts, 0.7)
         timed("f2f", f2f, args.reps, B, "frame-pairs")
     if not only or "reloc" in only:
         nt = args.shard

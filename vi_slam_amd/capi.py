@@ -84,6 +84,7 @@ SIGNATURES = {
                                       C.c_size_t, _P]),
     "vfe_match_workspace": (C.c_size_t, [C.c_int, C.c_longlong]),
     "vfe_dev_match_knn2": (C.c_int, [_P, C.c_int, _P, C.c_longlong, C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "vfe_dev_match_knn2_batch": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P]),
     "vfe_dev_merge_knn2": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "vfe_dev_ratio_test": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P]),
     "vfe_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
@@ -360,6 +361,21 @@ def match_knn2(query, train, base_index=0):
     check(lib().vfe_dev_match_knn2(_ptr(query), nq, _ptr(train) if nt else None, nt, base_index, _ptr(idx), _ptr(dist),
                                    _ptr(ws), nbytes, _stream()))
     return idx, dist
+
+
+def match_knn2_batch(query, nq, train, nt, ratio=0.7):
+    """query [B, qcap, 32], train [B, tcap, 32] uint8 cuda, nq/nt [B] int32 cuda ->
+    (idx [B, qcap, 2], dist [B, qcap, 2] int32, good [B, qcap] uint8)."""
+    import torch
+    b, qcap, _ = query.shape
+    tcap = train.shape[1]
+    assert query.is_contiguous() and train.is_contiguous()
+    idx = torch.empty((b, qcap, 2), dtype=torch.int32, device=query.device)
+    dist = torch.empty((b, qcap, 2), dtype=torch.int32, device=query.device)
+    good = torch.empty((b, qcap), dtype=torch.uint8, device=query.device)
+    check(lib().vfe_dev_match_knn2_batch(_ptr(query), _ptr(nq), qcap, _ptr(train), _ptr(nt), tcap, b, _ptr(idx), _ptr(dist),
+                                         ratio, _ptr(good), _stream()))
+    return idx, dist, good
 
 
 def merge_knn2(shard_idx, shard_dist):

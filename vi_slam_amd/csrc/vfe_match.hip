@@ -75,6 +75,50 @@ __global__ __launch_bounds__(256) void k_ratio(const int* __restrict__ idx, cons
     good[q] = (idx[2 * q] >= 0 && idx[2 * q + 1] >= 0 && (float)dist[2 * q] < ratio * (float)dist[2 * q + 1]) ? 1 : 0;
 }
 
+/* Batched frame-to-frame matching: workgroup (x, b) serves 64 queries of frame b; its four waves scan
+ * a quarter of that frame's train rows each and merge their top-2 lists through LDS.  Set sizes come
+ * from device memory, so extraction and matching can be queued back to back. */
+__global__ __launch_bounds__(256) void k_match_batch(const u32* __restrict__ query, const int* __restrict__ nq_dev, int q_cap,
+                                                     const u32* __restrict__ train, const int* __restrict__ nt_dev, int t_cap,
+                                                     int* __restrict__ out_idx, int* __restrict__ out_dist, float ratio,
+                                                     uint8_t* __restrict__ good) {
+    __shared__ int s_i[4][64][2], s_d[4][64][2];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nq = min(max(nq_dev[b], 0), q_cap), nt = min(max(nt_dev[b], 0), t_cap);
+    const int q = blockIdx.x * 64 + lane;
+    const u32* qp = query + ((size_t)b * q_cap + min(q, q_cap - 1)) * 8;
+    u32 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = qp[k];
+    /* workgroups past the last query only write the 'no neighbour' records */
+    const int per = (nt + 3) / 4, t0 = wv * per, t1 = (int)blockIdx.x * 64 < nq ? min(t0 + per, nt) : t0;
+    const u32* tb = train + (size_t)b * t_cap * 8;
+    int d0 = NO_DIST, d1 = NO_DIST, i0 = NO_IDX, i1 = NO_IDX;
+    for (int t = t0; t < t1; t++) {
+        const u32* tr = tb + (size_t)t * 8; /* wave-uniform address: scalar loads */
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d += __popc(a[k] ^ tr[k]);
+        if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = t; }
+        else if (d < d1) { d1 = d; i1 = t; }
+    }
+    s_i[wv][lane][0] = i0; s_i[wv][lane][1] = i1; s_d[wv][lane][0] = d0; s_d[wv][lane][1] = d1;
+    __syncthreads();
+    if (wv == 0 && q < q_cap) {
+        d0 = d1 = NO_DIST; i0 = i1 = NO_IDX;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                if (s_i[w][lane][k] >= 0) top2_insert(s_d[w][lane][k], s_i[w][lane][k], d0, i0, d1, i1);
+        if (q >= nq) { d0 = d1 = NO_DIST; i0 = i1 = NO_IDX; }
+        const size_t o = ((size_t)b * q_cap + q) * 2;
+        out_idx[o] = i0; out_idx[o + 1] = i1;
+        out_dist[o] = d0; out_dist[o + 1] = d1;
+        if (good) good[(size_t)b * q_cap + q] = (i0 >= 0 && i1 >= 0 && (float)d0 < ratio * (float)d1) ? 1 : 0;
+    }
+}
+
 static int match_chunk(int nq, long long nt) {
     /* enough (query block x chunk) workgroups to fill 256 CUs several times, chunks >= 64 rows */
     const long long qblocks = (nq + MT_THREADS - 1) / MT_THREADS;
@@ -139,6 +183,19 @@ extern "C" int vfe_dev_merge_knn2(const int* shard_idx, const int* shard_dist, i
 extern "C" int vfe_dev_ratio_test(const int* idx, const int* dist, int nq, float ratio, uint8_t* good, void* stream) {
     VFE_REQUIRE(idx && dist && good && nq > 0, "NULL buffer or nq <= 0");
     hipLaunchKernelGGL(k_ratio, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, dist, nq, ratio, good);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
+extern "C" int vfe_dev_match_knn2_batch(const uint8_t* query, const int* nq, int q_cap,
+                                        const uint8_t* train, const int* nt, int t_cap, int batch,
+                                        int* out_idx, int* out_dist, float ratio, uint8_t* good, void* stream) {
+    VFE_REQUIRE(query && train && nq && nt && out_idx && out_dist, "NULL buffer");
+    VFE_REQUIRE(q_cap > 0 && t_cap > 0 && batch > 0 && batch <= 65535, "bad sizes");
+    VFE_REQUIRE((uintptr_t)query % 4 == 0 && (uintptr_t)train % 4 == 0, "descriptors must be 4-byte aligned");
+    ProfScope prof(VFE_K_MATCH, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_match_batch, dim3((q_cap + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const u32*)query, nq, q_cap, (const u32*)train, nt, t_cap, out_idx, out_dist, ratio, good);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
