@@ -88,41 +88,8 @@ __global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u3
     dst.frame(b)[(size_t)y * dst.pitch + x] = (uint8_t)((v + (1u << 15)) >> 16);
 }
 
-/* ---- 7x7 Gaussian, sigma 2, 8.8 fixed point: taps 18 34 48 56 48 34 18 ------------------- */
-#define GB_TW 64
-#define GB_TH 16
-__global__ __launch_bounds__(256) void k_orb_blur(DImg src, DImg dst, int tiles_x, unsigned tiles_per_frame, unsigned total_work) {
-    __shared__ uint8_t s_in[GB_TH + 6][GB_TW + 8];
-    __shared__ unsigned short s_h[GB_TH + 6][GB_TW];
-    const int tid = threadIdx.x;
-    const int W = src.w, H = src.h;
-    for (unsigned work = blockIdx.x; work < total_work; work += gridDim.x) {
-        const int b = work / tiles_per_frame, tile = work - b * tiles_per_frame;
-        const int ox = (tile % tiles_x) * GB_TW, oy = (tile / tiles_x) * GB_TH;
-        const uint8_t* ip = src.frame(b);
-        for (int i = tid; i < (GB_TH + 6) * (GB_TW + 6); i += 256) {
-            const int r = i / (GB_TW + 6), c = i - r * (GB_TW + 6);
-            s_in[r][c] = ip[(size_t)reflect101(min(oy - 3 + r, H + 2), H) * src.pitch + reflect101(min(ox - 3 + c, W + 2), W)];
-        }
-        __syncthreads();
-        for (int i = tid; i < (GB_TH + 6) * GB_TW; i += 256) {
-            const int r = i / GB_TW, c = i - r * GB_TW;
-            const uint8_t* p = &s_in[r][c];
-            s_h[r][c] = (unsigned short)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
-        }
-        __syncthreads();
-        for (int i = tid; i < GB_TH * GB_TW; i += 256) {
-            const int r = i / GB_TW, c = i - r * GB_TW;
-            const int px = ox + c, py = oy + r;
-            if (px < W && py < H) {
-                const u32 v = 18u * (s_h[r][c] + s_h[r + 6][c]) + 34u * (s_h[r + 1][c] + s_h[r + 5][c]) +
-                              48u * (s_h[r + 2][c] + s_h[r + 4][c]) + 56u * s_h[r + 3][c];
-                dst.frame(b)[(size_t)py * dst.pitch + px] = (uint8_t)((v + (1u << 15)) >> 16);
-            }
-        }
-        __syncthreads();
-    }
-}
+/* 7x7 Gaussian, sigma 2 (vfe_orb_blur.hip) */
+int orb_blur_launch(const DImg& src, const DImg& dst, hipStream_t st);
 
 /* ---- keypoint selection --------------------------------------------------------------------- */
 struct OrbLevels {
@@ -520,10 +487,7 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
     }
     for (int l = 0; l < nlevels; l++) {
         ProfScope prof(VFE_K_ORB_BLUR, st);
-        const int tiles_x = div_up(W.w[l], GB_TW), tiles_y = div_up(W.h[l], GB_TH);
-        const unsigned tpf = (unsigned)(tiles_x * tiles_y), total = tpf * (unsigned)batch;
-        hipLaunchKernelGGL(k_orb_blur, dim3(total < 2048u ? total : 2048u), dim3(256), 0, st, L.raw[l], L.blur[l], tiles_x, tpf, total);
-        VFE_LAUNCH_CHECK();
+        if ((rc = orb_blur_launch(L.raw[l], L.blur[l], st))) return rc;
     }
     {
         ProfScope prof(VFE_K_ORB_DESC, st);
