@@ -91,132 +91,18 @@ __global__ __launch_bounds__(256) void k_pyr_down(DImg src, DImg dst, int tiles_
     }
 }
 
-/* ---- streaming variant (16-byte aligned images) -------------------------------------------------
- * One wavefront owns a strip of 62 x 8 output columns and walks down a band of output rows.  Per
- * source row each lane issues one coalesced 16-byte load (1 KiB per wave), takes the three halo
- * bytes it needs from its neighbours by shuffles, forms 8 horizontal [1 4 6 4 1] sums as packed
- * pairs of 16-bit values and keeps the last five rows of sums in registers; every second source row
- * it emits one output row (8 bytes per lane).  Source rows are requested several rows ahead so
- * that HBM latency overlaps the arithmetic.  No LDS, no barriers. */
-#define PS_OUT_LANES 62
-#define PS_AHEAD 4
-
-/* Source bytes IX0 .. IX0+15 of row iy.  Chunks entirely left of the image, or entirely right of
- * it when the width is a multiple of 16, are never read: the only bytes a neighbour would take
- * from them are reflections that the neighbour already holds (fixed up after the shuffle). */
-__device__ static inline uint4 pyr_load_row(const DImg& src, const uint8_t* sp, int iy, int IX0, bool w16) {
-    const uint8_t* row = sp + (size_t)reflect101(iy, src.h) * src.pitch;
-    if (IX0 >= 0 && IX0 + 15 < src.w) return *reinterpret_cast<const uint4*>(row + IX0);
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (!w16 && IX0 + 15 >= src.w && IX0 <= src.w + 16) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) w[k >> 2] |= (uint32_t)row[reflect101(IX0 + k, src.w)] << (8 * (k & 3));
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-__global__ __launch_bounds__(256) void k_pyr_down2(DImg src, DImg dst, int strips_x, int band_h, int bands_y, unsigned total_work) {
-    const int lane = threadIdx.x & 63;
-    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
-    const unsigned per_frame = (unsigned)(strips_x * bands_y);
-    for (unsigned work = wave; work < total_work; work += nwaves) {
-        const int b = work / per_frame, t = work - b * per_frame;
-        const int sxi = t % strips_x, byi = t / strips_x;
-        const int X0 = (sxi * PS_OUT_LANES + lane - 1) * 8; /* first output column of this lane */
-        const int IX0 = 2 * X0;                             /* source column of byte 0 of its 16-byte load */
-        const int oy0 = byi * band_h, oy1 = min(oy0 + band_h, dst.h);
-        const uint8_t* sp = src.frame(b);
-        uint8_t* dp = dst.frame(b);
-        const bool out_lane = lane >= 1 && lane <= PS_OUT_LANES && X0 < dst.w;
-        const int iy0 = 2 * oy0 - 2, iy1 = 2 * (oy1 - 1) + 2;
-        const bool w16 = (src.w & 15) == 0;
-        const bool fix_l = (IX0 == 0), fix_r = w16 && (IX0 + 16 == src.w);
-
-        uint4 pre[PS_AHEAD];
-#pragma unroll
-        for (int k = 0; k < PS_AHEAD; k++) pre[k] = pyr_load_row(src, sp, iy0 + k, IX0, w16);
-        uint32_t h[5][4]; /* five rows of 8 sums, two 16-bit sums per dword */
-#pragma unroll
-        for (int i = 0; i < 5; i++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) h[i][k] = 0;
-
-        for (int iy = iy0; iy <= iy1; iy++) {
-            const uint4 cur = pre[0];
-#pragma unroll
-            for (int k = 0; k < PS_AHEAD - 1; k++) pre[k] = pre[k + 1];
-            if (iy + PS_AHEAD <= iy1) pre[PS_AHEAD - 1] = pyr_load_row(src, sp, iy + PS_AHEAD, IX0, w16);
-            /* halo bytes: source columns IX0-2, IX0-1 (left lane's bytes 14, 15) and IX0+16 (right lane's byte 0) */
-            const uint32_t lw = (uint32_t)__shfl_up((int)cur.w, 1), rx = (uint32_t)__shfl_down((int)cur.x, 1);
-            const uint32_t d[4] = {cur.x, cur.y, cur.z, cur.w};
-            uint32_t E[4], O[4]; /* even / odd source bytes as packed pairs: E[i] = in[4i] | in[4i+2] << 16 */
-#pragma unroll
-            for (int i = 0; i < 4; i++) { E[i] = d[i] & 0x00FF00FFu; O[i] = (d[i] >> 8) & 0x00FF00FFu; }
-            /* in[-2], in[-1], in[16]; at the image rim they are reflections this lane already holds */
-            const uint32_t El = fix_l ? ((cur.x >> 16) & 0xFFu) : ((lw >> 16) & 0xFFu);
-            const uint32_t Ol = fix_l ? ((cur.x >> 8) & 0xFFu) : (lw >> 24);
-            const uint32_t Er = fix_r ? ((cur.w >> 16) & 0xFFu) : (rx & 0xFFu);
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                if (i < 4) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) h[i][k] = h[i + 1][k];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                /* outputs 2i, 2i+1 of this lane: sum_k = E[k-1] + 6 E[k] + E[k+1] + 4 (O[k-1] + O[k]) with E, O indexed by output */
-                const uint32_t Ep = (i == 0) ? El : (E[i - 1] >> 16);
-                const uint32_t Em1 = (E[i] << 16) | Ep;                                   /* E[k-1] pair */
-                const uint32_t En = (i == 3) ? Er : (E[i + 1] & 0xFFFFu);
-                const uint32_t Ep1 = (E[i] >> 16) | (En << 16);                           /* E[k+1] pair */
-                const uint32_t Op = (i == 0) ? Ol : (O[i - 1] >> 16);
-                const uint32_t Om1 = (O[i] << 16) | Op;                                   /* O[k-1] pair */
-                h[4][i] = Em1 + 6u * E[i] + Ep1 + 4u * (Om1 + O[i]);
-            }
-            const int done = iy - iy0;
-            if (done >= 4 && ((done & 1) == 0)) {
-                const int oy = (iy - 2) >> 1;
-                uint32_t v[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t s = h[0][k] + 4u * h[1][k] + 6u * h[2][k] + 4u * h[3][k] + h[4][k] + 0x00800080u;
-                    v[k] = (s >> 8) & 0x00FF00FFu; /* two result bytes in bits 0..7 and 16..23 */
-                }
-                const uint32_t o0 = (v[0] & 0xFFu) | ((v[0] >> 8) & 0xFF00u) | ((v[1] & 0xFFu) << 16) | ((v[1] & 0xFF0000u) << 8);
-                const uint32_t o1 = (v[2] & 0xFFu) | ((v[2] >> 8) & 0xFF00u) | ((v[3] & 0xFFu) << 16) | ((v[3] & 0xFF0000u) << 8);
-                if (out_lane) {
-                    uint8_t* drow = dp + (size_t)oy * dst.pitch + X0;
-                    if (X0 + 7 < dst.w) {
-                        *reinterpret_cast<uint2*>(drow) = make_uint2(o0, o1);
-                    } else {
-                        const uint32_t oo[2] = {o0, o1};
-                        for (int k = 0; k < 8 && X0 + k < dst.w; k++) drow[k] = (uint8_t)(oo[k >> 2] >> (8 * (k & 3)));
-                    }
-                }
-            }
-        }
-    }
-}
+/* streaming kernel for 16-byte aligned images (vfe_pyramid_stream.hip) */
+bool pyr_down_stream_ok(const DImg& s, const DImg& d);
+int pyr_down_stream_launch(const DImg& s, const DImg& d, hipStream_t st, bool* padded);
 
 static bool dword_ok(const DImg& d) {
     return ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
 }
-static bool vec_ok(const DImg& d, int align) {
-    return d.sub_n == 1 && ((uintptr_t)d.data % align == 0) && (d.pitch % align == 0) && (d.fstride % align == 0);
-}
-
-static int launch_pyr_down(const DImg& s, const DImg& d, hipStream_t st) {
-    if (vec_ok(s, 16) && vec_ok(d, 8)) {
-        const int strips_x = div_up(div_up(d.w, 8), PS_OUT_LANES);
-        int band_h = 64;
-        while (band_h > 8 && (long long)strips_x * div_up(d.h, band_h) * d.batch < 8192) band_h /= 2;
-        const int bands_y = div_up(d.h, band_h);
-        const unsigned total = (unsigned)(strips_x * bands_y * d.batch), nblk = (total + 3) / 4;
+static int launch_pyr_down(const DImg& s, const DImg& d, hipStream_t st, bool* padded) {
+    *padded = false;
+    if (pyr_down_stream_ok(s, d)) {
         ProfScope prof(VFE_K_PYR_DOWN, st);
-        hipLaunchKernelGGL(k_pyr_down2, dim3(nblk < 4096u ? nblk : 4096u), dim3(256), 0, st, s, d, strips_x, band_h, bands_y, total);
-        VFE_LAUNCH_CHECK();
-        return VFE_OK;
+        return pyr_down_stream_launch(s, d, st, padded);
     }
     const int tiles_x = div_up(d.w, PD_TW), tiles_y = div_up(d.h, PD_TH);
     const unsigned tpf = (unsigned)(tiles_x * tiles_y), total = tpf * (unsigned)d.batch;
@@ -289,8 +175,9 @@ extern "C" int vfe_dev_pyr_down(const vfe_dimg* src, const vfe_dimg* dst, void* 
     VFE_REQUIRE(dst->width == (src->width + 1) / 2 && dst->height == (src->height + 1) / 2, "dst must be ((w+1)/2, (h+1)/2)");
     VFE_REQUIRE(dst->batch == src->batch, "batch mismatch");
     VFE_REQUIRE(src->batch <= 65535, "batch too large");
-    if ((rc = launch_pyr_down(to_dimg(src), to_dimg(dst), (hipStream_t)stream))) return rc;
-    return launch_pad_border(to_dimg(dst), (hipStream_t)stream);
+    bool padded = false;
+    if ((rc = launch_pyr_down(to_dimg(src), to_dimg(dst), (hipStream_t)stream, &padded))) return rc;
+    return padded ? VFE_OK : launch_pad_border(to_dimg(dst), (hipStream_t)stream);
 }
 
 extern "C" int vfe_dev_build_pyramid(const vfe_dimg* levels, int nlevels, void* stream) {
