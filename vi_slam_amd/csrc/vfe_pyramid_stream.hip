@@ -32,11 +32,12 @@ template <int N> using ic = std::integral_constant<int, N>;
 /* Source bytes IX0 .. IX0+15 of row iy.  Chunks entirely left of the image, or entirely right of
  * it when the width is a multiple of 16, are never read: the only bytes a neighbour would take
  * from them are reflections that the neighbour already holds (fixed up after the shuffle). */
-__device__ static inline uint4 pyr_load_row(const DImg& src, const uint8_t* sp, int iy, int IX0, bool w16) {
+template <bool W16>
+__device__ static inline uint4 pyr_load_row(const DImg& src, const uint8_t* sp, int iy, int IX0) {
     const uint8_t* row = sp + (size_t)reflect101(iy, src.h) * src.pitch;
     if (IX0 >= 0 && IX0 + 15 < src.w) return *reinterpret_cast<const uint4*>(row + IX0);
     uint32_t w[4] = {0, 0, 0, 0};
-    if (!w16 && IX0 + 15 >= src.w && IX0 <= src.w + 16) {
+    if (!W16 && IX0 + 15 >= src.w && IX0 <= src.w + 16) {
 #pragma unroll
         for (int k = 0; k < 16; k++) w[k >> 2] |= (uint32_t)row[reflect101(IX0 + k, src.w)] << (8 * (k & 3));
     }
@@ -62,7 +63,8 @@ __device__ static inline void pyr_hsums(const uint4& c, u32 lw, u32 rb, u32 (&hp
     for (int i = 0; i < 4; i++) hp[i] = r[2 * i] | (r[2 * i + 1] << 16);
 }
 
-template <bool PAD>
+/* W16: the source width is a multiple of 16 (no lane straddles the right rim) */
+template <bool PAD, bool W16>
 __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int strips_x, int band_h, int bands_y, unsigned total_work) {
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
@@ -78,8 +80,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
         uint8_t* dp = dst.frame(b);
         const bool out_lane = lane >= 1 && lane <= PS_OUT_LANES && X0 < DW;
         const bool full_lane = out_lane && X0 + 7 < DW;
-        const bool w16 = (src.w & 15) == 0;
-        const bool fix_l = (IX0 == 0), fix_r = w16 && (IX0 + 16 == src.w);
+        const bool fix_l = (IX0 == 0), fix_r = W16 && (IX0 + 16 == src.w);
         /* lanes that also write a margin (PAD only; DW is a multiple of 8 there) */
         const bool rim_strip = PAD && (sxi == 0 || (sxi + 1) * PS_OUT_LANES * 8 + 8 > DW - 40);
         const bool padl8 = out_lane && X0 <= 24, padl1 = out_lane && X0 == 32;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
         const int iy0 = 2 * oy0 - 2, iy1 = 2 * oy1; /* source rows iy0 .. iy1 */
         uint4 pre[PS_AHEAD];
 #pragma unroll
-        for (int k = 0; k < PS_AHEAD; k++) pre[k] = (iy0 + k <= iy1) ? pyr_load_row(src, sp, iy0 + k, IX0, w16) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < PS_AHEAD; k++) pre[k] = (iy0 + k <= iy1) ? pyr_load_row<W16>(src, sp, iy0 + k, IX0) : make_uint4(0, 0, 0, 0);
         u32 A[3][4]; /* accumulators of three consecutive output rows, two 16-bit sums per dword */
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
             u32 hp[4];
             {   /* even row 2m */
                 const uint4 cur = pre[2 * ph];
-                if (2 * m + PS_AHEAD <= iy1) pre[2 * ph] = pyr_load_row(src, sp, 2 * m + PS_AHEAD, IX0, w16);
+                if (2 * m + PS_AHEAD <= iy1) pre[2 * ph] = pyr_load_row<W16>(src, sp, 2 * m + PS_AHEAD, IX0);
                 u32 lw = (u32)__shfl_up((int)cur.w, 1), rb = (u32)__shfl_down((int)cur.x, 1) & 0xFFu;
                 /* at the image rim the halo bytes are reflections this lane already holds:
                  * bytes -2, -1 = bytes 2, 1; byte 16 = byte 14 */
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
             }
             {   /* odd row 2m+1 (not needed after the last output row; harmless then) */
                 const uint4 cur = pre[2 * ph + 1];
-                if (2 * m + 1 + PS_AHEAD <= iy1) pre[2 * ph + 1] = pyr_load_row(src, sp, 2 * m + 1 + PS_AHEAD, IX0, w16);
+                if (2 * m + 1 + PS_AHEAD <= iy1) pre[2 * ph + 1] = pyr_load_row<W16>(src, sp, 2 * m + 1 + PS_AHEAD, IX0);
                 u32 lw = (u32)__shfl_up((int)cur.w, 1), rb = (u32)__shfl_down((int)cur.x, 1) & 0xFFu;
                 if (fix_l) lw = __builtin_amdgcn_perm(cur.x, cur.x, 0x01020c0cu);
                 if (fix_r) rb = (cur.w >> 16) & 0xFFu;
@@ -173,17 +174,42 @@ static bool vec_ok(const DImg& d, int align) {
 }
 bool pyr_down_stream_ok(const DImg& s, const DImg& d) { return vec_ok(s, 16) && vec_ok(d, 8); }
 
+typedef void (*pyr_kernel_t)(DImg, DImg, int, int, int, unsigned);
+
+/* waves of `kern` that fit one SIMD (512 VGPRs each, at most 8 waves) */
+static int waves_per_simd(pyr_kernel_t kern) {
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kern)) != hipSuccess || a.numRegs <= 0) return 4;
+    const int regs = (a.numRegs + 7) / 8 * 8;
+    const int w = 512 / regs;
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+
 /* *padded = the kernel also wrote dst's border */
 int pyr_down_stream_launch(const DImg& s, const DImg& d, hipStream_t st, bool* padded) {
+    const bool pad = d.border == PS_BORDER && d.w % 8 == 0 && d.w >= 48 && d.h >= PS_BORDER + 2;
+    const bool w16 = s.w % 16 == 0;
+    const pyr_kernel_t kern = pad ? (w16 ? k_pyr_down_stream<true, true> : k_pyr_down_stream<true, false>)
+                                  : (w16 ? k_pyr_down_stream<false, true> : k_pyr_down_stream<false, false>);
+    static int occ[4] = {0, 0, 0, 0};
+    int& o = occ[(pad ? 2 : 0) + (w16 ? 1 : 0)];
+    if (o == 0) o = waves_per_simd(kern);
+    /* Band height: every wave is an item (strip x band x frame) and all waves of a round run side by
+     * side, so the launch takes ceil(items / resident waves) rounds of (2 band + 9) source rows (two
+     * output rows of halo plus the prefetch ramp).  Pick the band height with the cheapest total. */
     const int strips_x = div_up(div_up(d.w, 8), PS_OUT_LANES);
-    int band_h = 64;
-    while (band_h > 8 && (long long)strips_x * div_up(d.h, band_h) * d.batch < 8192) band_h /= 2;
+    const long long slots = 256LL * 4 * o;
+    int band_h = 8;
+    long long best = -1;
+    for (int bh = 8; bh <= 128; bh += 2) {
+        const long long items = (long long)strips_x * div_up(d.h, bh) * d.batch;
+        const long long cost = ((items + slots - 1) / slots) * (2 * bh + 9);
+        if (best < 0 || cost < best) { best = cost; band_h = bh; }
+    }
     const int bands_y = div_up(d.h, band_h);
     const unsigned total = (unsigned)(strips_x * bands_y * d.batch), nblk = (total + 3) / 4;
     const dim3 grid(nblk < (1u << 20) ? nblk : (1u << 20));
-    const bool pad = d.border == PS_BORDER && d.w % 8 == 0 && d.w >= 48 && d.h >= PS_BORDER + 2;
-    if (pad) hipLaunchKernelGGL(k_pyr_down_stream<true>, grid, dim3(256), 0, st, s, d, strips_x, band_h, bands_y, total);
-    else hipLaunchKernelGGL(k_pyr_down_stream<false>, grid, dim3(256), 0, st, s, d, strips_x, band_h, bands_y, total);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, s, d, strips_x, band_h, bands_y, total);
     VFE_LAUNCH_CHECK();
     *padded = pad;
     return VFE_OK;
