@@ -72,6 +72,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(DImg img, int threshold, int
                                                     uint8_t* __restrict__ rowcnt, uint32_t* __restrict__ tmp) {
     __shared__ __align__(16) uint32_t s_imgw[FT_IH][FT_IW / 4];
     __shared__ uint8_t s_sc[FT_SH][FT_SW + 2];
+    __shared__ unsigned short s_queue[FT_SH * FT_SW];
+    __shared__ unsigned s_nq;
     const uint8_t* s_img = reinterpret_cast<const uint8_t*>(&s_imgw[0][0]);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int W = img.w, H = img.h;
@@ -95,13 +97,44 @@ __global__ __launch_bounds__(256) void k_fast_tiles(DImg img, int threshold, int
             s_imgw[r][k] = v;
         }
         __syncthreads();
-        for (int i = tid; i < FT_SH * FT_SW; i += 256) {
+        /* Pass 1, every position: the cheap necessary condition.  A 9-arc of the 16-pixel circle
+         * contains at least two of the four compass pixels, so a corner has two of them brighter
+         * than centre + t or two darker than centre - t.  Positions that pass are queued in LDS
+         * (one counter update per wave); the rest score 0.
+         * Pass 2, queued positions only, one per thread: the full arc test and score.  Few positions
+         * survive pass 1, so the expensive code runs densely packed instead of once per pixel. */
+        if (tid == 0) s_nq = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < FT_SH * FT_SW; i0 += 256) {
+            const int i = i0 + tid;
+            bool pass = false;
+            if (i < FT_SH * FT_SW) {
+                const int sy = i / FT_SW, sx = i - sy * FT_SW;
+                const int px = ox - 1 + sx, py = oy - 1 + sy;
+                if (px >= 3 && px < W - 3 && py >= 3 && py < H - 3) {
+                    const uint8_t* c = s_img + (sy + 3) * FT_IW + (sx + 3);
+                    const int v = c[0], hi = v + threshold, lo = v - threshold;
+                    const int p0 = c[3 * FT_IW], p4 = c[3], p8 = c[-3 * FT_IW], p12 = c[-3];
+                    const int nb = (p0 > hi) + (p4 > hi) + (p8 > hi) + (p12 > hi);
+                    const int nd = (p0 < lo) + (p4 < lo) + (p8 < lo) + (p12 < lo);
+                    pass = nb >= 2 || nd >= 2;
+                }
+                if (!pass) s_sc[sy][sx] = 0;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&s_nq, (unsigned)__popcll(m));
+                base = (unsigned)__shfl((int)base, 0);
+                if (pass) s_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            }
+        }
+        __syncthreads();
+        const int nq = (int)s_nq;
+        for (int j = tid; j < nq; j += 256) {
+            const int i = s_queue[j];
             const int sy = i / FT_SW, sx = i - sy * FT_SW;
-            const int px = ox - 1 + sx, py = oy - 1 + sy;
-            int sc = 0;
-            if (px >= 3 && px < W - 3 && py >= 3 && py < H - 3)
-                sc = fast_score(s_img + (sy + 3) * FT_IW + (sx + 3), threshold);
-            s_sc[sy][sx] = (uint8_t)sc;
+            s_sc[sy][sx] = (uint8_t)fast_score(s_img + (sy + 3) * FT_IW + (sx + 3), threshold);
         }
         __syncthreads();
 #pragma unroll
