@@ -146,6 +146,25 @@ int vfe_dev_klt_track(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, 
                       int win, int max_iter, double eps, double min_eig_thr, int use_initial_flow,
                       void* stream);
 
+/* Forward-backward check on top of vfe_dev_klt_track (`optical_flow_max_recovered_dist2`, reference
+ * docs/reference/17_basalt_smartphone_config.md:257; the reverse check of VINS-style front-ends): after
+ * the forward track, every point is tracked back next -> prev with its original position as the initial
+ * guess; status stays 1 only if both tracks succeeded and the squared distance between the recovered and
+ * the original position is <= max_recovered_dist2.  back_pts [batch][cap][2] (recovered positions) and
+ * back_status [batch][cap] are outputs/scratch. */
+int vfe_dev_klt_track_bidir(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                            const float* prev_pts, const int* n_pts, int pts_cap,
+                            float* next_pts, uint8_t* status, float* err, float* back_pts, uint8_t* back_status,
+                            int win, int max_iter, double eps, double min_eig_thr, double max_recovered_dist2,
+                            void* stream);
+
+/* cv::undistortPoints (no R, no P): pixel positions -> normalised, undistorted coordinates for the
+ * radial-tangential model the configs carry (`camera.k1, k2, p1, p2`, reference
+ * config/vins_mono.yaml:32-35).  camera4 = {fx, fy, cx, cy}, dist5 = {k1, k2, p1, p2, k3} (host
+ * arrays); pts/out [n][2] device, may alias. */
+int vfe_dev_undistort_points(const float* pts, float* out, long long n, const double* camera4, const double* dist5,
+                             void* stream);
+
 /* ---- batched front-end step ------------------------------------------------------------- */
 
 /* After tracking: keep the points with status != 0 whose rounded position lies inside

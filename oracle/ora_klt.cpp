@@ -171,3 +171,23 @@ extern "C" int ora_klt_track(const uint8_t* prev, const uint8_t* next, int w, in
     }
     return 0;
 }
+
+/* cv::undistortPoints for the radtan model (config/vins_mono.yaml:32-35 camera.k1..p2), no R / P:
+ * x0 = (u - cx)/fx; five iterations of x = (x0 - delta(x, y)) * icdist(x, y) in double. */
+extern "C" void ora_undistort_points(const float* pts, float* out, long long n, const double* cam4, const double* d5) {
+    const double fx = cam4[0], fy = cam4[1], cx = cam4[2], cy = cam4[3];
+    const double k1 = d5[0], k2 = d5[1], p1 = d5[2], p2 = d5[3], k3 = d5[4];
+    for (long long i = 0; i < n; i++) {
+        const double x0 = ((double)pts[2 * i] - cx) / fx, y0 = ((double)pts[2 * i + 1] - cy) / fy;
+        double x = x0, y = y0;
+        for (int it = 0; it < 5; it++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2);
+            const double dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+            const double dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+            x = (x0 - dx) * icdist;
+            y = (y0 - dy) * icdist;
+        }
+        out[2 * i] = (float)x; out[2 * i + 1] = (float)y;
+    }
+}

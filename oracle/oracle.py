@@ -156,6 +156,31 @@ def klt_track(prev, nxt, pts, win=21, max_level=3, max_iter=30, eps=0.01, min_ei
     return out, st, err
 
 
+def klt_track_bidir(prev, nxt, pts, max_recovered_dist2=0.04, win=21, max_level=3):
+    """Forward track, backward track from the original positions, float32 distance test."""
+    fwd, st, err = klt_track(prev, nxt, pts, win, max_level)
+    back, bst, _ = klt_track(nxt, prev, fwd, win, max_level, init=np.ascontiguousarray(pts, np.float32).reshape(-1, 2))
+    p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    dx = back[:, 0] - p[:, 0]
+    dy = back[:, 1] - p[:, 1]
+    d2 = dx * dx + dy * dy  # float32, one rounding per operation
+    ok = st.astype(bool) & bst.astype(bool) & (d2 <= np.float32(max_recovered_dist2))
+    return fwd, ok.astype(np.uint8), err, back
+
+
+def undistort_points(pts, camera, dist):
+    p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    out = np.empty_like(p)
+    cam = (C.c_double * 4)(*camera)
+    d5 = (C.c_double * 5)(*dist)
+    L = lib()
+    L.ora_undistort_points.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_longlong,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ora_undistort_points.restype = None
+    L.ora_undistort_points(_p(p, C.c_float), _p(out, C.c_float), len(p), cam, d5)
+    return out
+
+
 def fast9(img, threshold, nms=True):
     img, p = _u8(img)
     h, w = img.shape

@@ -50,6 +50,9 @@ int ora_klt_track(const uint8_t* prev, const uint8_t* next, int w, int h, int st
                   int win, int max_level, int max_iter, double eps, double min_eig_thr,
                   int use_initial_flow);
 
+/* cv::undistortPoints, radtan model, normalised output; cam4 = fx fy cx cy, d5 = k1 k2 p1 p2 k3 */
+void ora_undistort_points(const float* pts, float* out, long long n, const double* cam4, const double* d5);
+
 /* FAST-9/16 with 3x3 non-max suppression; keypoints in raster order as (x, y, score)
  * int triples.  Returns the count, or -1 if cap is too small. */
 int ora_fast9(const uint8_t* img, int w, int h, int step, int threshold, int nms,

@@ -180,6 +180,63 @@ def test_klt_parity(cuda, w, h, levels, npts):
         assert np.abs(np.median(flow, axis=0) - [-1.5, -0.75]).max() < 0.5
 
 
+def test_klt_forward_backward_check(cuda):
+    """Forward track + backward track from the original positions (OPTFLOW_USE_INITIAL_FLOW) + distance
+    test: statuses, forward and recovered positions equal the oracle's composition of the same steps."""
+    import torch
+    w, h, levels = 640, 360, 4
+    prev = [synth.scene(synth.BASE_SEED + 60 + s, w, h, 0) for s in range(2)]
+    # stream 0: the next frame; stream 1: four frames later plus noise, so that some points do not come back
+    nxt = [synth.scene(synth.BASE_SEED + 60, w, h, 1),
+           np.clip(synth.scene(synth.BASE_SEED + 61, w, h, 4).astype(np.int16) + (synth.noise(5, w, h) >> 3), 0, 255).astype(np.uint8)]
+    pts = [ora.good_features(p, 200, 0.01, 12)[0] for p in prev]
+    cap = max(len(p) for p in pts)
+    P = np.zeros((2, cap, 2), np.float32)
+    n = np.array([len(p) for p in pts], np.int32)
+    for i, p in enumerate(pts):
+        P[i, :len(p)] = p
+    pl = capi.build_pyramid(capi.alloc_pyramid(to_dev(prev, cuda), levels))
+    nl = capi.build_pyramid(capi.alloc_pyramid(to_dev(nxt, cuda), levels))
+    thr = 0.0025
+    out, st, err, back = capi.klt_track_bidir(pl, nl, torch.from_numpy(P).to(cuda), torch.from_numpy(n).to(cuda), thr)
+    out, st, err, back = out.cpu().numpy(), st.cpu().numpy(), err.cpu().numpy(), back.cpu().numpy()
+    rejected = 0
+    for i in range(2):
+        k = n[i]
+        ro, rs, re, rb = ora.klt_track_bidir(prev[i], nxt[i], pts[i], thr, 21, levels - 1)
+        fwd_only = ora.klt_track(prev[i], nxt[i], pts[i], 21, levels - 1)[1]
+        rejected += int(fwd_only.sum() - rs.sum())
+        assert np.array_equal(st[i, :k], rs)
+        assert np.array_equal(out[i, :k].view(np.uint32), ro.view(np.uint32))
+        assert np.array_equal(back[i, :k].view(np.uint32), rb.view(np.uint32))
+        assert np.array_equal(err[i, :k].view(np.uint32), re.view(np.uint32))
+        assert rs.sum() > 20
+    assert rejected > 0, "the check never rejected anything: the test does not exercise it"
+
+
+def test_undistort_points_bit_exact(cuda):
+    """cv::undistortPoints with the radtan coefficients of config/vins_mono.yaml-style calibrations."""
+    import torch
+    rng = np.random.default_rng(7)
+    pts = (rng.random((5000, 2)) * [752, 480]).astype(np.float32)
+    cam = (458.654, 457.296, 367.215, 248.375)
+    dist = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+    got = capi.undistort_points(torch.from_numpy(pts).to(cuda), cam, dist).cpu().numpy()
+    ref = ora.undistort_points(pts, cam, dist)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # sanity: re-distorting the result gives the pixel back
+    x, y = ref[:, 0].astype(np.float64), ref[:, 1].astype(np.float64)
+    r2 = x * x + y * y
+    rad = 1 + dist[0] * r2 + dist[1] * r2 * r2
+    xd = x * rad + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x)
+    yd = y * rad + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
+    ex, ey = np.abs(xd * cam[0] + cam[2] - pts[:, 0]), np.abs(yd * cam[1] + cam[3] - pts[:, 1])
+    # five fixed-point iterations (OpenCV's default) converge slowly towards the image corners
+    assert ex.max() < 0.5 and ey.max() < 0.5
+    centre = r2 < 0.1
+    assert centre.sum() > 500 and ex[centre].max() < 0.01 and ey[centre].max() < 0.01
+
+
 def _oracle_step(prev, cur, pts, n, q, d, levels, w, h):
     nxt, st, _ = ora.klt_track(prev, cur, pts, 21, levels - 1)
     r = np.rint(nxt)

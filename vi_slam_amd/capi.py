@@ -64,6 +64,9 @@ SIGNATURES = {
     "vfe_dev_min_eigen_map": (C.c_int, [_DI, _P, _P]),
     "vfe_dev_klt_track": (C.c_int, [_DI, _DI, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_double,
                                     C.c_double, C.c_int, _P]),
+    "vfe_dev_klt_track_bidir": (C.c_int, [_DI, _DI, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int,
+                                          C.c_double, C.c_double, C.c_double, _P]),
+    "vfe_dev_undistort_points": (C.c_int, [_P, _P, C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "vfe_dev_compact_tracks": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "vfe_dev_append_points": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "vfe_frontend_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -241,6 +244,34 @@ def klt_track(prev_levels, next_levels, prev_pts, n_pts=None, next_pts=None, sta
     check(lib().vfe_dev_klt_track(pa, na, n, _ptr(prev_pts), _ptr(n_pts), cap, _ptr(next_pts), _ptr(status),
                                   _ptr(err), win, max_iter, eps, min_eig_thr, 1 if use_initial_flow else 0, _stream()))
     return next_pts, status, err
+
+
+def klt_track_bidir(prev_levels, next_levels, prev_pts, n_pts=None, max_recovered_dist2=0.04,
+                    win=21, max_iter=30, eps=0.01, min_eig_thr=1e-4):
+    """Forward track + backward check; returns (next_pts, status, err, back_pts)."""
+    import torch
+    b, cap, _ = prev_pts.shape
+    next_pts = torch.zeros_like(prev_pts)
+    back = torch.zeros_like(prev_pts)
+    status = torch.zeros((b, cap), dtype=torch.uint8, device=prev_pts.device)
+    bstat = torch.zeros((b, cap), dtype=torch.uint8, device=prev_pts.device)
+    err = torch.zeros((b, cap), dtype=torch.float32, device=prev_pts.device)
+    n = len(prev_levels)
+    pa = (DImg * n)(*[dimg(t) for t in prev_levels])
+    na = (DImg * n)(*[dimg(t) for t in next_levels])
+    check(lib().vfe_dev_klt_track_bidir(pa, na, n, _ptr(prev_pts), _ptr(n_pts), cap, _ptr(next_pts), _ptr(status), _ptr(err),
+                                        _ptr(back), _ptr(bstat), win, max_iter, eps, min_eig_thr, max_recovered_dist2, _stream()))
+    return next_pts, status, err, back
+
+
+def undistort_points(pts, camera, dist):
+    """pts [..., 2] float32 cuda; camera (fx, fy, cx, cy); dist (k1, k2, p1, p2, k3)."""
+    import torch
+    out = torch.empty_like(pts)
+    cam = (C.c_double * 4)(*camera)
+    d5 = (C.c_double * 5)(*dist)
+    check(lib().vfe_dev_undistort_points(_ptr(pts.contiguous()), _ptr(out), pts.numel() // 2, cam, d5, _stream()))
+    return out
 
 
 def compact_tracks(pts, status, n_pts, width, height, border=1):
