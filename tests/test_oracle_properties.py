@@ -199,3 +199,38 @@ def test_match_contract_and_ties():
 def test_equalize_hist_spreads_range(img):
     e = ora.equalize_hist((img // 4 + 60).astype(np.uint8))
     assert e.min() == 0 and e.max() == 255
+
+
+def test_undistort_points_inverts_the_radtan_model():
+    """Distort normalised points with the plumb-bob model, project, undistort: the fixed-point iteration
+    recovers them (tightly near the principal point, where five iterations suffice)."""
+    rng = np.random.default_rng(11)
+    cam = (458.654, 457.296, 367.215, 248.375)
+    dist = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+    xy = (rng.random((2000, 2)) - 0.5) * 0.5  # |x|, |y| < 0.25
+    x, y = xy[:, 0], xy[:, 1]
+    r2 = x * x + y * y
+    rad = 1 + dist[0] * r2 + dist[1] * r2 * r2
+    xd = x * rad + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x)
+    yd = y * rad + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
+    px = np.stack([xd * cam[0] + cam[2], yd * cam[1] + cam[3]], axis=1).astype(np.float32)
+    und = ora.undistort_points(px, cam, dist)
+    assert np.abs(und - xy).max() < 2e-4
+    # without distortion it is the plain pinhole back-projection
+    und0 = ora.undistort_points(px, cam, (0, 0, 0, 0, 0))
+    assert np.allclose(und0[:, 0], (px[:, 0] - cam[2]) / cam[0], atol=1e-6)
+
+
+def test_forward_backward_check_keeps_consistent_tracks():
+    prev = synth.scene(synth.BASE_SEED + 70, 320, 240, 0)
+    nxt = synth.scene(synth.BASE_SEED + 70, 320, 240, 1)
+    pts, _ = ora.good_features(prev, 80, 0.01, 10)
+    fwd, ok, err, back = ora.klt_track_bidir(prev, nxt, pts, 0.04, 21, 2)
+    plain = ora.klt_track(prev, nxt, pts, 21, 2)
+    assert np.array_equal(fwd, plain[0]) and (ok <= plain[1]).all()
+    assert ok.sum() > 0.8 * len(pts)
+    d2 = ((back - pts) ** 2).sum(axis=1)
+    assert (d2[ok.astype(bool)] <= 0.04 + 1e-6).all()
+    # an impossible threshold rejects everything that moved at all
+    _, none, _, _ = ora.klt_track_bidir(prev, nxt, pts, 0.0, 21, 2)
+    assert none.sum() <= (d2 == 0).sum()
