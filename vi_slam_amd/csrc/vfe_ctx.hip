@@ -27,6 +27,12 @@ struct vfe_ctx {
     void* mws; size_t mws_bytes;        /* growable: match descriptors + workspace */
     int cur, have_prev, w, h;           /* stream state */
     int equalize; unsigned* eq_hist;    /* optional histogram equalisation of every uploaded frame */
+    /* pinned host memory: frames are repacked here row by row and leave in ONE contiguous copy (a pitched
+     * copy from pageable memory is done row by row by the runtime, ~4 ms per MB); results come back
+     * through h_io / h_small */
+    uint8_t* h_stage[2]; size_t stage_bytes;
+    char* h_io; size_t io_bytes;
+    int* h_small;
 };
 
 static int ctx_enter(vfe_ctx* c) {
@@ -61,12 +67,18 @@ static int ctx_upload(vfe_ctx* c, int slot, const uint8_t* data, int rows, int c
     VFE_REQUIRE(channels == 1 || channels == 3, "channels must be 1 (gray) or 3 (BGR)");
     VFE_REQUIRE(cols <= c->cfg.max_width && rows <= c->cfg.max_height, "image larger than the context was created for");
     VFE_REQUIRE(step >= (size_t)cols * channels, "step smaller than a row");
+    /* repack into the pinned staging buffer with the device pitch, then one contiguous copy */
+    uint8_t* hs = c->h_stage[slot & 1];
+    const size_t row_bytes = (size_t)cols * channels;
+    const size_t dpitch = channels == 1 ? (size_t)c->pitch[0] : (size_t)c->cfg.max_width * 3;
+    if (step == dpitch) memcpy(hs, data, dpitch * (size_t)(rows - 1) + row_bytes);
+    else for (int y = 0; y < rows; y++) memcpy(hs + (size_t)y * dpitch, data + (size_t)y * step, row_bytes);
+    const size_t total = dpitch * (size_t)(rows - 1) + row_bytes;
     if (channels == 1) {
-        VFE_HIP(hipMemcpy2DAsync(c->pyr[slot][0], c->pitch[0], data, step, cols, rows, hipMemcpyHostToDevice, c->stream));
+        VFE_HIP(hipMemcpyAsync(c->pyr[slot][0], hs, total, hipMemcpyHostToDevice, c->stream));
     } else {
-        const size_t bp = (size_t)c->cfg.max_width * 3;
-        VFE_HIP(hipMemcpy2DAsync(c->bgr, bp, data, step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, c->stream));
-        vfe_dimg s; s.data = c->bgr; s.width = cols; s.height = rows; s.pitch = (int)bp; s.batch = 1; s.frame_stride = bp * rows; s.border = 0;
+        VFE_HIP(hipMemcpyAsync(c->bgr, hs, total, hipMemcpyHostToDevice, c->stream));
+        vfe_dimg s; s.data = c->bgr; s.width = cols; s.height = rows; s.pitch = (int)dpitch; s.batch = 1; s.frame_stride = dpitch * rows; s.border = 0;
         vfe_dimg g = ctx_level(c, slot, 0, cols, rows);
         int rc = vfe_dev_bgr2gray(&s, &g, c->stream);
         if (rc) return rc;
@@ -88,6 +100,7 @@ extern "C" void vfe_destroy(vfe_ctx* c) {
     void* bufs[] = {c->bgr, c->pts, c->next_pts, c->corners, c->err, c->status, c->n_pts, c->n_tracked, c->counts,
                     c->ws, c->orb_kps, c->orb_desc, c->mws, c->eq_hist};
     for (void* p : bufs) (void)hipFree(p);
+    (void)hipHostFree(c->h_stage[0]); (void)hipHostFree(c->h_stage[1]); (void)hipHostFree(c->h_io); (void)hipHostFree(c->h_small);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -150,6 +163,14 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
     }
     c->ws_bytes = ws;
     CTX_TRY(hipMalloc(&c->ws, ws));
+    {
+        const size_t g = (size_t)c->pitch[0] * cfg->max_height, b3 = (size_t)cfg->max_width * 3 * cfg->max_height;
+        c->stage_bytes = g > b3 ? g : b3;
+        for (int s = 0; s < 2; s++) CTX_TRY(hipHostMalloc((void**)&c->h_stage[s], c->stage_bytes, hipHostMallocDefault));
+        c->io_bytes = N * 32 + (size_t)c->orb_cap * (sizeof(vfe_orb_kp) + 32) + 256;
+        CTX_TRY(hipHostMalloc((void**)&c->h_io, c->io_bytes, hipHostMallocDefault));
+        CTX_TRY(hipHostMalloc((void**)&c->h_small, 256, hipHostMallocDefault));
+    }
     CTX_TRY(hipStreamSynchronize(c->stream));
 #undef CTX_TRY
     *out = c;
@@ -183,10 +204,12 @@ extern "C" int vfe_detect_shi_tomasi(vfe_ctx* c, const uint8_t* data, int rows, 
     vfe_dimg img = ctx_level(c, slot, 0, cols, rows);
     if ((rc = vfe_dev_good_features(&img, max_corners, quality, min_distance, nullptr, nullptr, 0, c->corners, nullptr,
                                     c->counts, c->ws, c->ws_bytes, c->stream))) return rc;
-    int n = 0;
-    VFE_HIP(hipMemcpyAsync(&n, c->counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    /* the whole (small) corner buffer rides along with the count: one synchronisation */
+    VFE_HIP(hipMemcpyAsync(c->h_small, c->counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(c->h_io, c->corners, (size_t)max_corners * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     VFE_HIP(hipStreamSynchronize(c->stream));
-    if (n > 0) VFE_HIP(hipMemcpy(corners_xy, c->corners, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    const int n = c->h_small[0];
+    if (n > 0) memcpy(corners_xy, c->h_io, (size_t)n * 2 * sizeof(float));
     *n_out = n;
     return VFE_OK;
 }
@@ -207,15 +230,24 @@ extern "C" int vfe_klt_track(vfe_ctx* c, const uint8_t* prev, const uint8_t* nex
     const int nlev = ctx_levels(c, 0, cols, rows, max_level, pl);
     ctx_levels(c, 1, cols, rows, max_level, nl);
     if ((rc = vfe_dev_build_pyramid(pl, nlev, c->stream)) || (rc = vfe_dev_build_pyramid(nl, nlev, c->stream))) return rc;
-    VFE_HIP(hipMemcpyAsync(c->pts, prev_pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    VFE_HIP(hipMemcpyAsync(c->n_tracked, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const size_t pb = (size_t)n * 2 * sizeof(float);
+    memcpy(c->h_io, prev_pts, pb);
+    c->h_small[8] = n;
+    VFE_HIP(hipMemcpyAsync(c->pts, c->h_io, pb, hipMemcpyHostToDevice, c->stream));
+    VFE_HIP(hipMemcpyAsync(c->n_tracked, &c->h_small[8], sizeof(int), hipMemcpyHostToDevice, c->stream));
     if ((rc = vfe_dev_klt_track(pl, nl, nlev, c->pts, c->n_tracked, c->cfg.max_features, c->next_pts, c->status, c->err,
                                 c->cfg.win_size, max_iter, eps, min_eig_thr, 0, c->stream))) return rc;
-    VFE_HIP(hipMemcpyAsync(next_pts, c->next_pts, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    VFE_HIP(hipMemcpyAsync(status, c->status, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (err) VFE_HIP(hipMemcpyAsync(err, c->err, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    char* o_pts = c->h_io + align_up(pb, 64);
+    char* o_err = o_pts + align_up(pb, 64);
+    char* o_st = o_err + align_up((size_t)n * sizeof(float), 64);
+    VFE_HIP(hipMemcpyAsync(o_pts, c->next_pts, pb, hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(o_st, c->status, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(o_err, c->err, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     VFE_HIP(hipMemsetAsync(c->n_pts, 0, sizeof(int), c->stream));
     VFE_HIP(hipStreamSynchronize(c->stream));
+    memcpy(next_pts, o_pts, pb);
+    memcpy(status, o_st, (size_t)n);
+    if (err) memcpy(err, o_err, (size_t)n * sizeof(float));
     return VFE_OK;
 }
 
@@ -234,12 +266,16 @@ extern "C" int vfe_orb_extract(vfe_ctx* c, const uint8_t* data, int rows, int co
     const int dcap = cap < c->orb_cap ? cap : c->orb_cap;
     if ((rc = vfe_dev_orb_extract(&img, nfeatures, scale_factor, nlevels, fast_threshold, c->orb_kps, c->orb_desc, dcap,
                                   c->counts, c->ws, c->ws_bytes, c->stream))) return rc;
-    int n = 0;
-    VFE_HIP(hipMemcpyAsync(&n, c->counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(c->h_small, c->counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VFE_HIP(hipStreamSynchronize(c->stream));
+    const int n = c->h_small[0];
     if (n > 0) {
-        VFE_HIP(hipMemcpy(kps, c->orb_kps, (size_t)n * sizeof(vfe_orb_kp), hipMemcpyDeviceToHost));
-        VFE_HIP(hipMemcpy(desc, c->orb_desc, (size_t)n * 32, hipMemcpyDeviceToHost));
+        char* o_d = c->h_io + align_up((size_t)n * sizeof(vfe_orb_kp), 64);
+        VFE_HIP(hipMemcpyAsync(c->h_io, c->orb_kps, (size_t)n * sizeof(vfe_orb_kp), hipMemcpyDeviceToHost, c->stream));
+        VFE_HIP(hipMemcpyAsync(o_d, c->orb_desc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+        VFE_HIP(hipStreamSynchronize(c->stream));
+        memcpy(kps, c->h_io, (size_t)n * sizeof(vfe_orb_kp));
+        memcpy(desc, o_d, (size_t)n * 32);
     }
     *n_out = n;
     return VFE_OK;
@@ -299,9 +335,10 @@ extern "C" int vfe_process_frame(vfe_ctx* c, const uint8_t* data, int rows, int 
         if ((rc = vfe_dev_frontend_step(pl, nl, nlev, c->pts, c->n_pts, c->n_tracked, max_corners, quality, min_distance,
                                         c->cfg.win_size, 30, 0.01, 1e-4, c->ws, c->ws_bytes, c->stream))) return rc;
     }
-    VFE_HIP(hipMemcpyAsync(&h_n[0], c->n_pts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    VFE_HIP(hipMemcpyAsync(&h_n[1], c->n_tracked, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(&c->h_small[0], c->n_pts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(&c->h_small[1], c->n_tracked, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VFE_HIP(hipStreamSynchronize(c->stream));
+    h_n[0] = c->h_small[0]; h_n[1] = c->h_small[1];
     c->cur = nxt; c->have_prev = 1; c->w = cols; c->h = rows;
     if (stats) { stats->n_total = h_n[0]; stats->n_tracked = h_n[1]; stats->n_detected = h_n[0] - h_n[1]; }
     return VFE_OK;
@@ -311,11 +348,12 @@ extern "C" int vfe_get_points(vfe_ctx* c, float* pts_xy, int cap, int* n_out) {
     int rc = ctx_enter(c);
     if (rc) return rc;
     VFE_REQUIRE(pts_xy && n_out && cap >= 0, "NULL output");
-    int n = 0;
-    VFE_HIP(hipMemcpyAsync(&n, c->n_pts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(c->h_small, c->n_pts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(c->h_io, c->pts, (size_t)c->cfg.max_features * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     VFE_HIP(hipStreamSynchronize(c->stream));
+    int n = c->h_small[0];
     if (n > cap) n = cap;
-    if (n > 0) VFE_HIP(hipMemcpy(pts_xy, c->pts, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (n > 0) memcpy(pts_xy, c->h_io, (size_t)n * 2 * sizeof(float));
     *n_out = n;
     return VFE_OK;
 }
