@@ -85,6 +85,9 @@ def main():
                     help="fraction of each stream's tracks dropped after every step (models feature loss, so that "
                          "every frame has corners to refill; the synthetic scene alone loses almost none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="multi-rank rehearsal on a box with one GPU: every rank uses cuda:0 and the barrier / max-reduce "
+                         "go over gloo (RCCL refuses two ranks on one device); not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -96,10 +99,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
+    if args.rehearse_one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     capi.lib()
 
     B = args.batch
@@ -155,7 +163,7 @@ def main():
     capi.prof_enable(False)
     prof = capi.prof_read(reset=True)
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_device else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
