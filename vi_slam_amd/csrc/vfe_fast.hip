@@ -219,10 +219,10 @@ FastWs fast_layout(int w, int h, int batch) {
     size_t o = 0;
     L.rowcnt_off = o; o += align_up((size_t)batch * h * L.tiles_x, 256);
     L.rowoff_off = o; o += align_up((size_t)batch * h * L.tiles_x * sizeof(uint32_t), 256);
-    {   /* per-tile slots of the tiled kernel or per-segment slots of the streaming one, whichever is larger */
-        const size_t tiled = (size_t)batch * L.tiles_x * L.tiles_y * FT_TH * FT_ROWCAP;
-        const size_t stream = (size_t)batch * h * div_up(w, FS_OUT) * FS_ROWCAP;
-        L.tmp_off = o; o += align_up((tiled > stream ? tiled : stream) * sizeof(uint32_t), 256);
+    L.tmp_off = o; o += align_up((size_t)batch * L.tiles_x * L.tiles_y * FT_TH * FT_ROWCAP * sizeof(uint32_t), 256);
+    {   /* whole frames go through the streaming kernels, which lay the workspace out themselves */
+        const size_t stream = fast_set_layout(1, &w, &h, batch).total;
+        if (stream > o) o = stream;
     }
     L.total = o;
     return L;
@@ -238,12 +238,10 @@ int fast_detect(const DImg& d, int threshold, int border, int* kps, int cap, int
                          (d.sub_n == 1 || (d.sub_dx % 4 == 0 && d.sub_dy % 4 == 0));
     dim3 grid(total < 2048u ? total : 2048u);
     ProfScope prof(VFE_K_FAST, st);
-    if (d.sub_n == 1 && d.w >= 16 && d.h >= 16) { /* whole frames: streaming kernel */
-        int rc = fast_stream_launch(d, threshold, border, rowcnt, tmp, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_fast_scan, dim3(d.batch), dim3(1024), 0, st, rowcnt, rowoff, d.h * div_up(d.w, FS_OUT), counts, cap);
-        VFE_LAUNCH_CHECK();
-        return fast_scatter_stream_launch(d, rowcnt, rowoff, tmp, kps, cap, st);
+    if (d.sub_n == 1 && d.w >= 16 && d.h >= 16) { /* whole frames: streaming kernels */
+        FastSet S;
+        S.n = 1; S.img[0] = fast_img(d); S.kps[0] = kps; S.counts[0] = counts; S.cap[0] = cap;
+        return fast_detect_set(S, d.batch, threshold, border, ws, st);
     }
     if (aligned)
         hipLaunchKernelGGL(k_fast_tiles<true>, grid, dim3(256), 0, st, d, threshold, border, L.tiles_x, tpf, total, rowcnt, tmp);

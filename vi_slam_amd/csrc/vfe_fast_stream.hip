@@ -1,23 +1,30 @@
 /* FAST-9/16 score + 3x3 non-max suppression for whole frames, streaming (cv::FAST semantics, same
- * scores and raster order as the tiled kernel in vfe_fast.hip).
+ * scores and raster order as the tiled kernel in vfe_fast.hip).  One launch serves a set of images of
+ * different sizes (the levels of an ORB pyramid), so that small levels fill the gaps large ones leave.
  *
  * One wavefront owns a strip of 62 x 4 columns (lanes 0 and 63 are halo) and walks down a band of rows.
  * A lane keeps the last seven image rows as three dwords each (its own four bytes and the neighbours'),
  * so every pixel of the 16-pixel circle is a byte of a register.  Two horizontally adjacent pixels are
  * scored together in packed 16-bit arithmetic:
  *   score = max(t, max over 9-arcs of min(d), -min over 9-arcs of max(d)) - 1,   d = centre - circle,
- * with the sliding minima / maxima built by doubling (2, 4, 8, 9 wide); a pixel is a corner iff the
- * bracket exceeds t.  Before that, a necessary condition on the four compass pixels (each opposite
- * pair must hold a pixel that differs from the centre by more than t) is evaluated for the whole wave:
- * if no lane passes, the pair is skipped.  Scores of three rows stay in registers for the 3x3
- * suppression; keypoints of a row segment are numbered in raster order with ballots and written to
- * the segment's slot together with the segment's count. */
+ * a pixel is a corner iff the bracket exceeds t.  The sixteen 9-arc minima come from suffix minima of
+ * d[k..7], d[k..15] and prefix minima of d[0..k], d[8..k]: arc k..k+8 is one suffix plus the prefix
+ * eight places on (28 + 16 operations instead of 64 by doubling).  Before that, a necessary condition
+ * on the four compass pixels (each opposite pair must hold a pixel that differs from the centre by more
+ * than t) is evaluated for the whole wave: if no lane passes, the pair is skipped.  Scores of three rows
+ * stay in registers for the 3x3 suppression; keypoints of a row segment are numbered in raster order
+ * with ballots and written to the segment's slot together with the segment's count.
+ *
+ * The row loop is unrolled seven times so that the image ring's slots are compile-time constants; a
+ * band is 7k - 8 rows high so that every wave runs whole periods. */
 #include "vfe_common.h"
 #include "vfe_fast.h"
+#include <type_traits>
 
 typedef unsigned int u32;
 typedef short s2v __attribute__((ext_vector_type(2)));
 typedef unsigned short u2v __attribute__((ext_vector_type(2)));
+template <int N> using ic = std::integral_constant<int, N>;
 
 __device__ static inline s2v as_s(u32 v) { return __builtin_bit_cast(s2v, v); }
 __device__ static inline u32 as_u(s2v v) { return __builtin_bit_cast(u32, v); }
@@ -27,9 +34,9 @@ __device__ static inline s2v pmax(s2v a, s2v b) { return __builtin_elementwise_m
 __device__ static inline s2v splat(int v) { return s2v{(short)v, (short)v}; }
 
 /* bytes i and i+1 (1 <= i <= 9) of the 12-byte window {l, c, r} as a pair of 16-bit values */
-__device__ static inline s2v win_pair(u32 l, u32 c, u32 r, int i) {
-    if (i + 1 <= 7) return as_s(__builtin_amdgcn_perm(c, l, 0x0c000c00u | (u32)i | ((u32)(i + 1) << 16)));
-    return as_s(__builtin_amdgcn_perm(r, c, 0x0c000c00u | (u32)(i - 4) | ((u32)(i - 3) << 16)));
+__device__ static inline s2v win_pair(const u32 (&row)[3], int i) {
+    if (i + 1 <= 7) return as_s(__builtin_amdgcn_perm(row[1], row[0], 0x0c000c00u | (u32)i | ((u32)(i + 1) << 16)));
+    return as_s(__builtin_amdgcn_perm(row[2], row[1], 0x0c000c00u | (u32)(i - 4) | ((u32)(i - 3) << 16)));
 }
 
 /* circle position k -> (dx, dy), dy positive = down (the order of cv::FAST's offsets) */
@@ -38,87 +45,92 @@ __device__ static inline s2v win_pair(u32 l, u32 c, u32 r, int i) {
 #define FS_DY(k) ((k) == 0 ? 3 : (k) == 1 ? 3 : (k) == 2 ? 2 : (k) == 3 ? 1 : (k) == 4 ? 0 : (k) == 5 ? -1 : (k) == 6 ? -2 : (k) == 7 ? -3 : \
                   (k) == 8 ? -3 : (k) == 9 ? -3 : (k) == 10 ? -2 : (k) == 11 ? -1 : (k) == 12 ? 0 : (k) == 13 ? 1 : (k) == 14 ? 2 : 3)
 
-/* scores of the pixel pair (px, px+1) of the centre row R[3]; px = 0 or 2 within the lane's four pixels */
-template <int PX>
+/* scores of the pixel pair (px, px+1) of the centre row; px = 0 or 2 within the lane's four pixels.  The ring
+ * slot PH holds the newest row (centre + 3), so centre + dy sits in slot (PH + 4 + dy) mod 7. */
+template <int PX, int PH>
 __device__ static inline u32 fast_score_pair(const u32 (&R)[7][3], int t) {
-    const s2v v = win_pair(R[3][0], R[3][1], R[3][2], PX + 4);
-    /* compass pixels first: a 9-arc holds one pixel of each opposite pair */
-    s2v p[16];
+#define FS_ROW(dy) R[(PH + 4 + (dy) + 7) % 7]
+    const s2v v = win_pair(FS_ROW(0), PX + 4);
+    s2v d[16];
 #pragma unroll
-    for (int k = 0; k < 16; k += 4) p[k] = win_pair(R[3 + FS_DY(k)][0], R[3 + FS_DY(k)][1], R[3 + FS_DY(k)][2], PX + FS_DX(k) + 4);
+    for (int k = 0; k < 16; k += 4) d[k] = v - win_pair(FS_ROW(FS_DY(k)), PX + FS_DX(k) + 4);
     bool pass;
-    {
-        const s2v a0 = pmax(v - p[0], p[0] - v), a8 = pmax(v - p[8], p[8] - v);
-        const s2v a4 = pmax(v - p[4], p[4] - v), a12 = pmax(v - p[12], p[12] - v);
+    {   /* compass pixels first: a 9-arc holds one pixel of each opposite pair */
+        const s2v a0 = pmax(d[0], splat(0) - d[0]), a8 = pmax(d[8], splat(0) - d[8]);
+        const s2v a4 = pmax(d[4], splat(0) - d[4]), a12 = pmax(d[12], splat(0) - d[12]);
         const s2v m = pmin(pmax(a0, a8), pmax(a4, a12));
         pass = m.x > (short)t || m.y > (short)t;
     }
     if (__ballot(pass) == 0) return 0u;
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        if (k & 3) p[k] = win_pair(R[3 + FS_DY(k)][0], R[3 + FS_DY(k)][1], R[3 + FS_DY(k)][2], PX + FS_DX(k) + 4);
-    s2v d[16], mn[16], mx[16];
+        if (k & 3) d[k] = v - win_pair(FS_ROW(FS_DY(k)), PX + FS_DX(k) + 4);
+#undef FS_ROW
+    /* arc k .. k+8 = d[k .. end of its half] (a suffix extremum, kept running) and d[start of the other half .. k+8]
+     * (a prefix extremum of the other half) */
+    s2v a = splat(-32768), b = splat(32767);
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - p[k];
-    s2v mn2[16], mx2[16], mn4[16], mx4[16];
+    for (int h = 0; h < 16; h += 8) {
+        const int o = h ^ 8;
+        s2v pn[8], px[8];
+        pn[0] = px[0] = d[o];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { mn2[k] = pmin(d[k], d[(k + 1) & 15]); mx2[k] = pmax(d[k], d[(k + 1) & 15]); }
+        for (int j = 1; j < 8; j++) { pn[j] = pmin(d[o + j], pn[j - 1]); px[j] = pmax(d[o + j], px[j - 1]); }
+        s2v rn = d[h + 7], rx = d[h + 7];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { mn4[k] = pmin(mn2[k], mn2[(k + 2) & 15]); mx4[k] = pmax(mx2[k], mx2[(k + 2) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mn[k] = pmin(pmin(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        mx[k] = pmax(pmax(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        for (int j = 7; j >= 0; j--) {
+            if (j < 7) { rn = pmin(rn, d[h + j]); rx = pmax(rx, d[h + j]); }
+            a = pmax(a, pmin(rn, pn[j]));
+            b = pmin(b, pmax(rx, px[j]));
+        }
     }
-    s2v a = mn[0], b = mx[0];
-#pragma unroll
-    for (int k = 1; k < 16; k++) { a = pmax(a, mn[k]); b = pmin(b, mx[k]); }
     const s2v m = pmax(pmax(a, splat(t)), splat(0) - pmin(b, splat(-t))); /* >= t; > t iff corner */
     const s2v e = m - splat(t);
     /* score = m - 1 for corners, 0 otherwise */
     return as_u(pmin(e, splat(1)) * (e + splat(t - 1)));
 }
 
-template <bool ALIGNED>
-__global__ __launch_bounds__(256) void k_fast_stream(DImg img, int threshold, int border, int strips_x, int band_h, int bands_y,
-                                                     unsigned total_work, uint8_t* __restrict__ rowcnt, u32* __restrict__ tmp) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_stream(FastSet S, int threshold, int border, uint8_t* __restrict__ rowcnt, u32* __restrict__ tmp) {
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
-    const int W = img.w, H = img.h;
-    const unsigned per_frame = (unsigned)(strips_x * bands_y);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const unsigned total_work = S.item_begin[S.n];
     for (unsigned work = wave; work < total_work; work += nwaves) {
-        const int b = work / per_frame, t_item = work - (unsigned)b * per_frame;
+        int lv = 0;
+        while (lv + 1 < S.n && work >= S.item_begin[lv + 1]) lv++;
+        const FastImg img = S.img[lv];
+        const int strips_x = S.strips_x[lv], band_h = S.band_h;
+        const int W = img.w, H = img.h;
+        const unsigned per_frame = (unsigned)(strips_x * S.bands_y[lv]);
+        const unsigned item = work - S.item_begin[lv];
+        const int b = item / per_frame, t_item = item - (unsigned)b * per_frame;
         const int sxi = t_item % strips_x, byi = t_item / strips_x;
         const int X0 = sxi * FS_OUT + 4 * (lane - 1); /* image column of this lane's pixel 0 */
-        const int y0 = byi * band_h, y1 = min(y0 + band_h, H);
-        const uint8_t* ip = img.frame(b);
-        const bool fast_load = ALIGNED && X0 >= 0 && X0 + 3 < W;
+        const int y0 = byi * band_h;
+        const uint8_t* ip = img.data + (size_t)b * img.fstride;
+        const bool fast_load = img.aligned && X0 >= 0 && X0 + 3 < W;
         const bool out_lane = lane >= 1 && lane < 63;
+        const size_t seg0 = (size_t)S.seg_begin[lv] + (size_t)b * H * strips_x + sxi;
         /* per pixel: may be scored (circle inside the image), may be reported */
-        u32 score_mask = 0; /* 0xFFFF per scorable pixel, as two pair masks */
         u32 smask[2] = {0, 0};
         bool rep[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = X0 + k;
             if (x >= 3 && x < W - 3) smask[k >> 1] |= 0xFFFFu << (16 * (k & 1));
-            rep[k] = out_lane && x >= border && x < W - border && x < W;
+            rep[k] = out_lane && x >= border && x < W - border;
         }
-        (void)score_mask;
 
-        u32 R[7][3];  /* image rows yy-6 .. yy: left neighbour's, own, right neighbour's dword */
-        u32 S[3][3];  /* score rows N-2 .. N: pixel pairs (0,1), (2,3) as 16-bit values, and s[-1] | s[4] << 16 */
+        u32 R[7][3]; /* image rows: left neighbour's, own, right neighbour's dword; the row of step t in slot t mod 7 */
+        u32 SC[3][3]; /* score rows N-2 .. N: pixel pairs (0,1), (2,3) as 16-bit values, and s[-1] | s[4] << 16 */
 #pragma unroll
         for (int i = 0; i < 7; i++) R[i][0] = R[i][1] = R[i][2] = 0;
 #pragma unroll
-        for (int i = 0; i < 3; i++) S[i][0] = S[i][1] = S[i][2] = 0;
+        for (int i = 0; i < 3; i++) SC[i][0] = SC[i][1] = SC[i][2] = 0;
 
-        const int T = (y1 - y0) + 8; /* image rows y0-4 .. y1+3 */
-        for (int t = 0; t < T; t++) {
+        /* stc: 0 = load only, 1 = also score row yy - 3, 2 = also (if t >= 8) report row yy - 4 */
+        auto step = [&](auto phc, auto stc, int t) {
+            constexpr int PH = decltype(phc)::value, ST = decltype(stc)::value;
             const int yy = y0 - 4 + t;
-#pragma unroll
-            for (int i = 0; i < 6; i++) { R[i][0] = R[i + 1][0]; R[i][1] = R[i + 1][1]; R[i][2] = R[i + 1][2]; }
             {
                 /* rows and columns outside the image are never part of a scored circle: clamp */
                 const uint8_t* row = ip + (size_t)min(max(yy, 0), H - 1) * img.pitch;
@@ -126,37 +138,37 @@ __global__ __launch_bounds__(256) void k_fast_stream(DImg img, int threshold, in
                 if (fast_load) c = *reinterpret_cast<const uint32_t*>(row + X0);
                 else c = (u32)row[min(max(X0, 0), W - 1)] | ((u32)row[min(max(X0 + 1, 0), W - 1)] << 8) |
                          ((u32)row[min(max(X0 + 2, 0), W - 1)] << 16) | ((u32)row[min(max(X0 + 3, 0), W - 1)] << 24);
-                R[6][1] = c;
-                R[6][0] = (u32)__shfl_up((int)c, 1);
-                R[6][2] = (u32)__shfl_down((int)c, 1);
+                R[PH][1] = c;
+                R[PH][0] = (u32)__shfl_up((int)c, 1);
+                R[PH][2] = (u32)__shfl_down((int)c, 1);
             }
-            if (t < 6) continue;
+            if constexpr (ST < 1) return;
             /* ---- scores of row N = yy - 3 ---- */
             const int N = yy - 3;
 #pragma unroll
-            for (int i = 0; i < 2; i++) { S[i][0] = S[i + 1][0]; S[i][1] = S[i + 1][1]; S[i][2] = S[i + 1][2]; }
+            for (int i = 0; i < 2; i++) { SC[i][0] = SC[i + 1][0]; SC[i][1] = SC[i + 1][1]; SC[i][2] = SC[i + 1][2]; }
             {
                 u32 s01 = 0, s23 = 0;
                 if (N >= 3 && N < H - 3) { /* wave-uniform */
-                    s01 = fast_score_pair<0>(R, threshold) & smask[0];
-                    s23 = fast_score_pair<2>(R, threshold) & smask[1];
+                    s01 = fast_score_pair<0, PH>(R, threshold) & smask[0];
+                    s23 = fast_score_pair<2, PH>(R, threshold) & smask[1];
                 }
-                S[2][0] = s01; S[2][1] = s23;
+                SC[2][0] = s01; SC[2][1] = s23;
                 const u32 sl = (u32)__shfl_up((int)s23, 1) >> 16, sr = (u32)__shfl_down((int)s01, 1) & 0xFFFFu;
-                S[2][2] = sl | (sr << 16);
+                SC[2][2] = sl | (sr << 16);
             }
-            if (t < 8) continue;
-            /* ---- suppression and output of row M = yy - 4 (score rows M-1, M, M+1 = S[0], S[1], S[2]) ---- */
+            if constexpr (ST < 2) return;
+            /* ---- suppression and output of row M = yy - 4 (score rows M-1, M, M+1 = SC[0], SC[1], SC[2]) ---- */
             const int M = yy - 4;
-            const size_t seg = ((size_t)b * H + M) * strips_x + sxi;
-            bool kp[4] = {false, false, false, false};
-            if (__ballot((S[1][0] | S[1][1]) != 0) != 0) {
+            if (t < 8 || M >= H) return; /* wave-uniform */
+            int total = 0;
+            if (__ballot((SC[1][0] | SC[1][1]) != 0) != 0 && M >= border && M < H - border) {
                 u2v nb01, nb23; /* largest of the eight neighbours */
                 {
                     u2v h01[3], h23[3];
 #pragma unroll
                     for (int i = 0; i < 3; i++) {
-                        const u32 p01 = S[i][0], p23 = S[i][1], e = S[i][2];
+                        const u32 p01 = SC[i][0], p23 = SC[i][1], e = SC[i][2];
                         const u2v L01 = as_uh(__builtin_amdgcn_perm(p01, e, 0x05040100u));    /* (s[-1], s0) */
                         const u2v M12 = as_uh(__builtin_amdgcn_perm(p23, p01, 0x05040302u));  /* (s1, s2) */
                         const u2v R23 = as_uh(__builtin_amdgcn_perm(e, p23, 0x07060302u));    /* (s3, s4) */
@@ -171,41 +183,56 @@ __global__ __launch_bounds__(256) void k_fast_stream(DImg img, int threshold, in
                     nb01 = __builtin_elementwise_max(__builtin_elementwise_max(h01[0], h01[1]), h01[2]);
                     nb23 = __builtin_elementwise_max(__builtin_elementwise_max(h23[0], h23[1]), h23[2]);
                 }
-                const u2v c01 = as_uh(S[1][0]), c23 = as_uh(S[1][1]);
-                const bool rowok = M >= border && M < H - border;
-                kp[0] = rowok && rep[0] && c01.x > nb01.x;
-                kp[1] = rowok && rep[1] && c01.y > nb01.y;
-                kp[2] = rowok && rep[2] && c23.x > nb23.x;
-                kp[3] = rowok && rep[3] && c23.y > nb23.y;
-            }
-            const unsigned long long m0 = __ballot(kp[0]), m1 = __ballot(kp[1]), m2 = __ballot(kp[2]), m3 = __ballot(kp[3]);
-            const int total = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
-            if (total) {
-                int pos = __popcll(m0 & lt_mask) + __popcll(m1 & lt_mask) + __popcll(m2 & lt_mask) + __popcll(m3 & lt_mask);
-                u32* dst = tmp + seg * FS_ROWCAP;
-                const u32 sc[4] = {S[1][0] & 0xFFFFu, S[1][0] >> 16, S[1][1] & 0xFFFFu, S[1][1] >> 16};
+                const u2v c01 = as_uh(SC[1][0]), c23 = as_uh(SC[1][1]);
+                const bool kp[4] = {rep[0] && c01.x > nb01.x, rep[1] && c01.y > nb01.y, rep[2] && c23.x > nb23.x, rep[3] && c23.y > nb23.y};
+                const unsigned long long m0 = __ballot(kp[0]), m1 = __ballot(kp[1]), m2 = __ballot(kp[2]), m3 = __ballot(kp[3]);
+                total = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+                if (total) {
+                    /* keypoints of lower lanes come first, then this lane's in pixel order */
+                    u32 pos = 0;
+                    pos = __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, pos));
+                    pos = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, pos));
+                    pos = __builtin_amdgcn_mbcnt_hi((u32)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m2, pos));
+                    pos = __builtin_amdgcn_mbcnt_hi((u32)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m3, pos));
+                    u32* dst = tmp + (seg0 + (size_t)M * strips_x) * FS_ROWCAP;
+                    const u32 sc[4] = {SC[1][0] & 0xFFFFu, SC[1][0] >> 16, SC[1][1] & 0xFFFFu, SC[1][1] >> 16};
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (kp[k]) { dst[pos] = (u32)(4 * (lane - 1) + k) | (sc[k] << 8); pos++; }
+                    for (int k = 0; k < 4; k++)
+                        if (kp[k]) { dst[pos] = (u32)(4 * (lane - 1) + k) | (sc[k] << 8); pos++; }
+                }
             }
-            if (lane == 0) rowcnt[seg] = (uint8_t)total;
+            if (lane == 0) rowcnt[seg0 + (size_t)M * strips_x] = (uint8_t)total;
+        };
+
+        /* image rows y0-4 .. y0+band_h+3, band_h + 8 = whole periods of seven steps; rows past the image are
+         * loaded clamped, scored as 0 and not reported */
+        step(ic<0>{}, ic<0>{}, 0); step(ic<1>{}, ic<0>{}, 1); step(ic<2>{}, ic<0>{}, 2); step(ic<3>{}, ic<0>{}, 3);
+        step(ic<4>{}, ic<0>{}, 4); step(ic<5>{}, ic<0>{}, 5); step(ic<6>{}, ic<1>{}, 6);
+        const int T = band_h + 8;
+        for (int t0 = 7; t0 < T; t0 += 7) {
+            if (y0 - 4 + t0 - 4 >= H) break; /* nothing left to report (wave-uniform) */
+            step(ic<0>{}, ic<2>{}, t0); step(ic<1>{}, ic<2>{}, t0 + 1); step(ic<2>{}, ic<2>{}, t0 + 2); step(ic<3>{}, ic<2>{}, t0 + 3);
+            step(ic<4>{}, ic<2>{}, t0 + 4); step(ic<5>{}, ic<2>{}, t0 + 5); step(ic<6>{}, ic<2>{}, t0 + 6);
         }
     }
 }
 
 /* one thread per (frame, row, strip) segment copies the segment's keypoints to their final offset */
-__global__ __launch_bounds__(256) void k_fast_scatter_stream(int H, int strips_x, unsigned n_seg, const uint8_t* __restrict__ rowcnt,
-                                                             const u32* __restrict__ rowoff, const u32* __restrict__ tmp,
-                                                             int* __restrict__ kps, int cap) {
+__global__ __launch_bounds__(256) void k_fast_scatter_stream(FastSet S, const uint8_t* __restrict__ rowcnt, const u32* __restrict__ rowoff,
+                                                             const u32* __restrict__ tmp) {
     const unsigned seg = blockIdx.x * 256u + threadIdx.x;
-    if (seg >= n_seg) return;
+    if (seg >= S.seg_begin[S.n]) return;
     const int n = rowcnt[seg];
     if (n == 0) return;
-    const unsigned per_frame = (unsigned)(H * strips_x);
-    const int b = seg / per_frame;
-    const unsigned r = seg - (unsigned)b * per_frame;
+    int lv = 0;
+    while (lv + 1 < S.n && seg >= S.seg_begin[lv + 1]) lv++;
+    const int H = S.img[lv].h, strips_x = S.strips_x[lv], cap = S.cap[lv];
+    const unsigned per_frame = (unsigned)(H * strips_x), ls = seg - S.seg_begin[lv];
+    const int b = ls / per_frame;
+    const unsigned r = ls - (unsigned)b * per_frame;
     const int y = r / strips_x, sxi = r - y * strips_x;
     const u32 off0 = rowoff[seg];
+    int* kps = S.kps[lv];
     for (int j = 0; j < n; j++) {
         const u32 e = tmp[(size_t)seg * FS_ROWCAP + j];
         const u32 off = off0 + j;
@@ -216,24 +243,94 @@ __global__ __launch_bounds__(256) void k_fast_scatter_stream(int H, int strips_x
     }
 }
 
-int fast_stream_launch(const DImg& d, int threshold, int border, uint8_t* rowcnt, u32* tmp, hipStream_t st) {
-    const int strips_x = div_up(d.w, FS_OUT);
-    int band_h = 64;
-    while (band_h > 16 && (long long)strips_x * div_up(d.h, band_h) * d.batch < 16384) band_h /= 2;
-    const int bands_y = div_up(d.h, band_h);
-    const unsigned total = (unsigned)(strips_x * bands_y * d.batch), nblk = (total + 3) / 4;
-    const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
-    const dim3 grid(nblk < (1u << 20) ? nblk : (1u << 20));
-    if (aligned) hipLaunchKernelGGL(k_fast_stream<true>, grid, dim3(256), 0, st, d, threshold, border, strips_x, band_h, bands_y, total, rowcnt, tmp);
-    else hipLaunchKernelGGL(k_fast_stream<false>, grid, dim3(256), 0, st, d, threshold, border, strips_x, band_h, bands_y, total, rowcnt, tmp);
+/* exclusive prefix of rowcnt over the (row, strip) segments of one frame of one level, in raster order;
+ * one workgroup per (frame, level) */
+__global__ __launch_bounds__(1024) void k_fast_scan_stream(FastSet S, const uint8_t* __restrict__ rowcnt, u32* __restrict__ rowoff) {
+    __shared__ u32 s_buf[2][1024];
+    const int b = blockIdx.x, lv = blockIdx.y, tid = threadIdx.x;
+    const int n_per_frame = S.img[lv].h * S.strips_x[lv];
+    const uint8_t* rc = rowcnt + S.seg_begin[lv] + (size_t)b * n_per_frame;
+    u32* ro = rowoff + S.seg_begin[lv] + (size_t)b * n_per_frame;
+    const int per = (n_per_frame + 1023) / 1024;
+    const int i0 = min(tid * per, n_per_frame), i1 = min(i0 + per, n_per_frame);
+    u32 sum = 0;
+    for (int i = i0; i < i1; i++) sum += rc[i];
+    int cur = 0;
+    s_buf[0][tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        u32 x = s_buf[cur][tid];
+        if (tid >= o) x += s_buf[cur][tid - o];
+        s_buf[cur ^ 1][tid] = x;
+        cur ^= 1;
+        __syncthreads();
+    }
+    u32 run = s_buf[cur][tid] - sum;
+    for (int i = i0; i < i1; i++) { ro[i] = run; run += rc[i]; }
+    if (tid == 1023) S.counts[lv][b] = (int)min(s_buf[cur][1023], (u32)S.cap[lv]);
+}
+
+static int fast_set_geometry(FastSet& S, int batch) {
+    /* band height 7k - 8; the tallest that still gives every SIMD several items */
+    static const int heights[5] = {62, 34, 27, 20, 13};
+    int band_h = 13;
+    for (int i = 0; i < 5; i++) {
+        long long items = 0;
+        for (int l = 0; l < S.n; l++) items += (long long)div_up(S.img[l].w, FS_OUT) * div_up(S.img[l].h, heights[i]) * batch;
+        if (items >= 12288) { band_h = heights[i]; break; }
+    }
+    S.band_h = band_h;
+    unsigned long long items = 0, segs = 0;
+    for (int l = 0; l < S.n; l++) {
+        S.strips_x[l] = div_up(S.img[l].w, FS_OUT);
+        S.bands_y[l] = div_up(S.img[l].h, band_h);
+        S.item_begin[l] = (unsigned)items; S.seg_begin[l] = (unsigned)segs;
+        items += (unsigned long long)S.strips_x[l] * S.bands_y[l] * batch;
+        segs += (unsigned long long)S.strips_x[l] * S.img[l].h * batch;
+    }
+    if (items >= (1ull << 31) || segs >= (1ull << 31)) { vfe_set_error("FAST: image set too large"); return VFE_E_INVALID; }
+    S.item_begin[S.n] = (unsigned)items; S.seg_begin[S.n] = (unsigned)segs;
+    return VFE_OK;
+}
+
+FastSetWs fast_set_layout(int n, const int* w, const int* h, int batch) {
+    FastSetWs L;
+    size_t segs = 0;
+    for (int l = 0; l < n; l++) segs += (size_t)div_up(w[l], FS_OUT) * h[l] * batch;
+    size_t o = 0;
+    L.rowcnt_off = o; o += align_up(segs, 256);
+    L.rowoff_off = o; o += align_up(segs * sizeof(u32), 256);
+    L.tmp_off = o; o += align_up(segs * FS_ROWCAP * sizeof(u32), 256);
+    L.total = o;
+    return L;
+}
+
+int fast_detect_set(FastSet& S, int batch, int threshold, int border, char* ws, hipStream_t st) {
+    if (S.n < 1 || S.n > FAST_MAX_LEVELS) { vfe_set_error("FAST: 1..%d images per set", FAST_MAX_LEVELS); return VFE_E_INVALID; }
+    int w[FAST_MAX_LEVELS], h[FAST_MAX_LEVELS];
+    for (int l = 0; l < S.n; l++) {
+        w[l] = S.img[l].w; h[l] = S.img[l].h;
+        if (w[l] < 16 || h[l] < 16) { vfe_set_error("FAST (streaming): image must be at least 16x16"); return VFE_E_INVALID; }
+    }
+    int rc = fast_set_geometry(S, batch);
+    if (rc) return rc;
+    const FastSetWs L = fast_set_layout(S.n, w, h, batch);
+    uint8_t* rowcnt = (uint8_t*)(ws + L.rowcnt_off);
+    u32* rowoff = (u32*)(ws + L.rowoff_off);
+    u32* tmp = (u32*)(ws + L.tmp_off);
+    const unsigned total = S.item_begin[S.n], nblk = (total + 3) / 4, n_seg = S.seg_begin[S.n];
+    hipLaunchKernelGGL(k_fast_stream, dim3(nblk < (1u << 20) ? nblk : (1u << 20)), dim3(256), 0, st, S, threshold, border, rowcnt, tmp);
+    VFE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fast_scan_stream, dim3(batch, S.n), dim3(1024), 0, st, S, rowcnt, rowoff);
+    VFE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fast_scatter_stream, dim3((n_seg + 255) / 256), dim3(256), 0, st, S, rowcnt, rowoff, tmp);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
 
-int fast_scatter_stream_launch(const DImg& d, const uint8_t* rowcnt, const u32* rowoff, const u32* tmp, int* kps, int cap, hipStream_t st) {
-    const int strips_x = div_up(d.w, FS_OUT);
-    const unsigned n_seg = (unsigned)d.batch * (unsigned)d.h * (unsigned)strips_x;
-    hipLaunchKernelGGL(k_fast_scatter_stream, dim3((n_seg + 255) / 256), dim3(256), 0, st, d.h, strips_x, n_seg, rowcnt, rowoff, tmp, kps, cap);
-    VFE_LAUNCH_CHECK();
-    return VFE_OK;
+FastImg fast_img(const DImg& d) {
+    FastImg f;
+    f.data = d.data; f.w = d.w; f.h = d.h; f.pitch = d.pitch; f.fstride = d.fstride;
+    f.aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
+    return f;
 }

@@ -402,12 +402,12 @@ static int orb_layout(int width, int height, int batch, float scale_factor, int 
         L->keep_off[l] = o; o += align_up((size_t)batch * L->cap[l], 256);
     }
     L->lvlcnt_off = o; o += align_up((size_t)batch * ORB_MAX_LEVELS * sizeof(int), 256);
-    L->fast_bytes = 0;
-    for (int l = 0; l < nlevels; l++)
-        if (L->w[l] >= 7 && L->h[l] >= 7) {
-            size_t f = fast_layout(L->w[l], L->h[l], batch).total;
-            if (f > L->fast_bytes) L->fast_bytes = f;
-        }
+    {   /* FAST runs on all levels at once (levels too small for the 31-pixel border yield nothing) */
+        int fw[ORB_MAX_LEVELS], fh[ORB_MAX_LEVELS], nf = 0;
+        for (int l = 0; l < nlevels; l++)
+            if (L->w[l] > 2 * ORB_EDGE && L->h[l] > 2 * ORB_EDGE) { fw[nf] = L->w[l]; fh[nf] = L->h[l]; nf++; }
+        L->fast_bytes = nf ? fast_set_layout(nf, fw, fh, batch).total : 0;
+    }
     L->fast_off = o; o += align_up(L->fast_bytes, 256);
     L->total = o;
     return VFE_OK;
@@ -469,14 +469,19 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
         hipLaunchKernelGGL(k_orb_resize, dim3(div_up(W.w[l], 256), W.h[l], batch), dim3(256), 0, st, L.raw[l - 1], L.raw[l], xtab, ytab);
         VFE_LAUNCH_CHECK();
     }
-    /* FAST per level (levels too small for the 31-pixel border yield nothing) */
-    for (int l = 0; l < nlevels; l++) {
-        if (W.w[l] > 2 * ORB_EDGE && W.h[l] > 2 * ORB_EDGE) {
-            if ((rc = fast_detect(L.raw[l], fast_threshold, ORB_EDGE, (int*)(ws + W.kps_off[l]), W.cap[l],
-                                  (int*)(ws + W.cnt_off[l]), ws + W.fast_off, st))) return rc;
-        } else {
-            VFE_HIP(hipMemsetAsync(ws + W.cnt_off[l], 0, (size_t)batch * sizeof(int), st));
+    {   /* FAST on all levels at once (levels too small for the 31-pixel border yield nothing) */
+        ProfScope prof(VFE_K_FAST, st);
+        FastSet F;
+        F.n = 0;
+        for (int l = 0; l < nlevels; l++) {
+            if (W.w[l] > 2 * ORB_EDGE && W.h[l] > 2 * ORB_EDGE) {
+                F.img[F.n] = fast_img(L.raw[l]); F.kps[F.n] = (int*)(ws + W.kps_off[l]); F.counts[F.n] = (int*)(ws + W.cnt_off[l]);
+                F.cap[F.n] = W.cap[l]; F.n++;
+            } else {
+                VFE_HIP(hipMemsetAsync(ws + W.cnt_off[l], 0, (size_t)batch * sizeof(int), st));
+            }
         }
+        if (F.n && (rc = fast_detect_set(F, batch, fast_threshold, ORB_EDGE, ws + W.fast_off, st))) return rc;
     }
     {
         ProfScope prof(VFE_K_ORB_SELECT, st);
