@@ -2,9 +2,12 @@
  *
  * Per call: exact-bilinear pyramid (fixed-point INTER_LINEAR_EXACT weights computed on the GPU in
  * IEEE double), FAST-9 + NMS per level (vfe_fast.hip), then per (frame, level):
- *   k_orb_select  retainBest(2*quota) on the FAST score via a 256-bin histogram, Harris response
- *                 of the survivors (7x7 block of integer Sobel products), retainBest(quota) on the
- *                 response via a 3-pass radix select over order-preserving keys (ties kept),
+ *   k_orb_hist    256-bin histogram of the FAST scores,
+ *   k_orb_harris  retainBest(2*quota) on the FAST score (smallest kept score from the histogram, ties
+ *                 kept), Harris response of the survivors (7x7 block of integer Sobel products, one
+ *                 wavefront per survivor, lanes = block positions),
+ *   k_orb_thresh  retainBest(quota) on the response via a 3-pass radix select over the survivors'
+ *                 order-preserving keys (ties kept),
  *   k_orb_emit    stable compaction into the frame's output list at the level's base offset, so
  *                 keypoints come out in (octave, y, x) order,
  * then a 7x7 sigma-2 fixed-point Gaussian of every level through LDS tiles, and
@@ -57,9 +60,16 @@ extern "C" int vfe_orb_quotas(int nfeatures, float scale_factor, int nlevels, in
 }
 
 /* ---- INTER_LINEAR_EXACT ------------------------------------------------------------------- */
-/* tab[v] = source offset << 9 | weight of the right/lower neighbour (0..256) */
-__global__ void k_orb_tables(int ssize, int dsize, u32* __restrict__ tab) {
+/* tab[v] = source offset << 9 | weight of the right/lower neighbour (0..256); blockIdx.y picks the table */
+struct OrbTabs {
+    int n;
+    int ssize[2 * ORB_MAX_LEVELS], dsize[2 * ORB_MAX_LEVELS];
+    u32* tab[2 * ORB_MAX_LEVELS];
+};
+__global__ void k_orb_tables(OrbTabs T) {
+    const int e = blockIdx.y;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ssize = T.ssize[e], dsize = T.dsize[e];
     if (v >= dsize) return;
     const double inv_scale = (double)dsize / (double)ssize;
     const double scale = 1.0 / inv_scale;
@@ -70,7 +80,7 @@ __global__ void k_orb_tables(int ssize, int dsize, u32* __restrict__ tab) {
         if (i < ssize - 1) { ofs = (u32)i; w1 = (u32)(int)rint((f - (double)i) * 256.0); }
         else ofs = (u32)(ssize - 1);
     }
-    tab[v] = (ofs << 9) | w1;
+    T.tab[e][v] = (ofs << 9) | w1;
 }
 
 __global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab) {
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u3
 }
 
 /* 7x7 Gaussian, sigma 2 (vfe_orb_blur.hip) */
-int orb_blur_launch(const DImg& src, const DImg& dst, hipStream_t st);
+int orb_blur_launch(const DImg* src, const DImg* dst, int n, hipStream_t st);
 
 /* ---- keypoint selection --------------------------------------------------------------------- */
 struct OrbLevels {
@@ -100,8 +110,11 @@ struct OrbLevels {
     int cap[ORB_MAX_LEVELS];          /* FAST keypoint capacity of the level */
     const int* kps[ORB_MAX_LEVELS];   /* [batch][cap][3] */
     const int* cnt[ORB_MAX_LEVELS];   /* [batch] */
-    u32* key[ORB_MAX_LEVELS];         /* [batch][cap] order-preserving Harris keys, 0 = dropped */
-    uint8_t* keep[ORB_MAX_LEVELS];    /* [batch][cap] */
+    u32* key[ORB_MAX_LEVELS];         /* [batch][cap] order-preserving Harris keys by FAST index, 0 = dropped */
+    u32* skey[ORB_MAX_LEVELS];        /* [batch][cap] keys of the survivors of the first cut, any order */
+    u32* hist;                        /* [batch][ORB_MAX_LEVELS][256] FAST score histogram (zeroed per call) */
+    u32* scnt;                        /* [batch][ORB_MAX_LEVELS] survivors of the first cut (zeroed per call) */
+    u32* thr;                         /* [batch][ORB_MAX_LEVELS] smallest kept key; 0 keeps nothing */
     int nlevels;
 };
 
@@ -113,118 +126,188 @@ __device__ static inline float key_float(u32 k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-__device__ static inline float harris_response(const uint8_t* img, int pitch, int x0, int y0) {
-    int a = 0, b = 0, c = 0;
-    for (int i = 0; i < 7; i++) {
-        const uint8_t* r0 = img + (size_t)(y0 - 4 + i) * pitch + (x0 - 4);
-        const uint8_t* r1 = r0 + pitch;
-        const uint8_t* r2 = r1 + pitch;
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const int Ix = (r1[j + 2] - r1[j]) * 2 + (r0[j + 2] - r0[j]) + (r2[j + 2] - r2[j]);
-            const int Iy = (r2[j + 1] - r0[j + 1]) * 2 + (r2[j] - r0[j]) + (r2[j + 2] - r0[j + 2]);
-            a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
-        }
-    }
-    const float scale = 1.f / ((float)((1 << 2) * 7) * 255.f);
-    const float scale4 = scale * scale * scale * scale;
-    const float fa = (float)a, fb = (float)b, fc = (float)c;
-    const float s = fa + fb;
-    return ((fa * fb - fc * fc) - (0.04f * s) * s) * scale4;
-}
+#define SEL_CHUNKS 32 /* workgroups per (level, frame) in the per-keypoint passes */
 
-__global__ __launch_bounds__(1024) void k_orb_select(OrbLevels L, int* __restrict__ lvl_count) {
-    __shared__ u32 s_hist[2048 + 1];
-    __shared__ u32 s_scan[2][1024];
-    __shared__ u32 s_val;
-    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_orb_hist(OrbLevels L) {
+    __shared__ u32 s_hist[256];
+    const int l = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const int cap = L.cap[l];
     const int n = min(L.cnt[l][b], cap);
+    if (n <= 2 * L.quota[l] || (int)(blockIdx.x * 256u) >= n) return; /* no first cut: histogram unused */
+    const int* kps = L.kps[l] + (size_t)b * cap * 3;
+    s_hist[tid] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + tid; i < n; i += SEL_CHUNKS * 256) atomicAdd(&s_hist[kps[3 * i + 2] & 255], 1u);
+    __syncthreads();
+    if (s_hist[tid]) atomicAdd(&L.hist[((size_t)b * ORB_MAX_LEVELS + l) * 256 + tid], s_hist[tid]);
+}
+
+/* sum over each row of 16 lanes, result in every lane of the row */
+__device__ static inline int row16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false);  /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false);  /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false); /* row_ror 4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); /* row_ror 8 */
+    return v;
+}
+
+#define HARRIS_KP 16      /* keypoints a wave looks at per pass: few, so that the survivors (often most of them)
+                           * spread over many waves */
+#define HARRIS_CHUNKS 128 /* single-wave workgroups per (level, frame) */
+
+__global__ __launch_bounds__(64) void k_orb_harris(OrbLevels L) {
+    __shared__ u32 s_xy[HARRIS_KP], s_key[HARRIS_KP];
+    const int l = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int cap = L.cap[l];
+    const int n = min(L.cnt[l][b], cap);
+    if ((int)(blockIdx.x * HARRIS_KP) >= n) return;
     const int* kps = L.kps[l] + (size_t)b * cap * 3;
     u32* key = L.key[l] + (size_t)b * cap;
-    uint8_t* keep = L.keep[l] + (size_t)b * cap;
+    u32* skey = L.skey[l] + (size_t)b * cap;
     const int quota = L.quota[l];
     const DImg& I = L.raw[l];
     const uint8_t* ip = I.frame(b);
+    const int pitch = I.pitch;
 
-    /* retainBest(2*quota) on the FAST score: smallest kept score */
+    /* retainBest(2*quota) on the FAST score: smallest kept score = largest s >= 1 with at least 2*quota
+     * scores >= s (0 if there is none).  Lane j holds bins 4j .. 4j+3. */
     int smin = 0;
     if (n > 2 * quota) {
         if (2 * quota == 0) smin = 256;
         else {
-            for (int i = tid; i < 256; i += 1024) s_hist[i] = 0;
+            const uint4 h = reinterpret_cast<const uint4*>(L.hist + ((size_t)b * ORB_MAX_LEVELS + l) * 256)[lane];
+            u32 S = h.x + h.y + h.z + h.w; /* becomes the number of scores >= 4 * lane */
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 t = (u32)__shfl_down((int)S, o);
+                if (lane + o < 64) S += t;
+            }
+            const u32 need = (u32)(2 * quota);
+            const unsigned long long ok = __ballot(S >= need);
+            if (ok) {
+                const int jh = 63 - __clzll((long long)ok);
+                int d = 4 * lane;
+                if (S - h.x >= need) d = 4 * lane + 1;
+                if (S - h.x - h.y >= need) d = 4 * lane + 2;
+                if (S - h.x - h.y - h.z >= need) d = 4 * lane + 3;
+                smin = __shfl(d, jh);
+            }
+        }
+    }
+    /* a row of 16 lanes works on one survivor; lane `sub` of the row takes positions sub, sub + 16, ... of the
+     * 7x7 block */
+    const int row = lane >> 4, sub = lane & 15;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int i0 = blockIdx.x * HARRIS_KP; i0 < n; i0 += HARRIS_CHUNKS * HARRIS_KP) { /* wave-uniform */
+        const int i = i0 + lane;
+        const bool mine = lane < HARRIS_KP && i < n;
+        int kx = 0, ky = 0;
+        bool surv = false;
+        if (mine) { kx = kps[3 * i]; ky = kps[3 * i + 1]; surv = kps[3 * i + 2] >= smin; }
+        const unsigned long long m = __ballot(surv);
+        const int cnt = __popcll(m);
+        const int slot = surv ? __popcll(m & lt_mask) : -1;
+        if (surv) s_xy[slot] = (u32)kx | ((u32)ky << 16);
+        __syncthreads();
+        for (int s0 = 0; s0 < cnt; s0 += 4) { /* wave-uniform */
+            const int sv = s0 + row;
+            int a = 0, bb = 0, c = 0;
+            if (sv < cnt) {
+                const u32 xy = s_xy[sv];
+                const uint8_t* base = ip + (size_t)((int)(xy >> 16) - 4) * pitch + ((int)(xy & 0xFFFFu) - 4);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int p = sub + 16 * r;
+                    if (p < 49) {
+                        const int py = p / 7, px = p - 7 * py;
+                        const uint8_t* r0 = base + (size_t)py * pitch + px;
+                        const uint8_t* r1 = r0 + pitch;
+                        const uint8_t* r2 = r1 + pitch;
+                        const int Ix = (r1[2] - r1[0]) * 2 + (r0[2] - r0[0]) + (r2[2] - r2[0]);
+                        const int Iy = (r2[1] - r0[1]) * 2 + (r2[0] - r0[0]) + (r2[2] - r0[2]);
+                        a += Ix * Ix; bb += Iy * Iy; c += Ix * Iy;
+                    }
+                }
+            }
+            a = row16_sum(a); bb = row16_sum(bb); c = row16_sum(c);
+            const float scale = 1.f / ((float)((1 << 2) * 7) * 255.f);
+            const float scale4 = scale * scale * scale * scale;
+            const float fa = (float)a, fb = (float)bb, fc = (float)c;
+            const float sm = fa + fb;
+            const float resp = ((fa * fb - fc * fc) - (0.04f * sm) * sm) * scale4;
+            if (sv < cnt && sub == 0) s_key[sv] = float_key(resp);
+        }
+        __syncthreads();
+        if (mine) key[i] = slot >= 0 ? s_key[slot] : 0u;
+        if (cnt) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&L.scnt[b * ORB_MAX_LEVELS + l], (u32)cnt);
+            base = (u32)__shfl((int)base, 0);
+            if (lane < cnt) skey[base + lane] = s_key[lane];
+        }
+        __syncthreads();
+    }
+}
+
+/* retainBest(quota) on the response: key of the quota-th largest among the survivors, ties kept */
+__global__ __launch_bounds__(1024) void k_orb_thresh(OrbLevels L, int* __restrict__ lvl_count) {
+    __shared__ u32 s_hist[2048 + 1];
+    __shared__ u32 s_scan[1024];
+    __shared__ u32 s_val;
+    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cap = L.cap[l];
+    const int quota = L.quota[l];
+    const u32 n1 = min(L.scnt[b * ORB_MAX_LEVELS + l], (u32)cap);
+    const u32* skey = L.skey[l] + (size_t)b * cap;
+    u32 T = 1; /* keep every survivor (keys are >= 1) */
+    if (quota == 0) T = 0;
+    else if (n1 > (u32)quota) {
+        u32 prefix = 0, need = (u32)quota;
+        int hi = 32;
+        while (hi > 0) {
+            const int bits = hi >= 11 ? 11 : hi, sh = hi - bits;
+            for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += 1024) atomicAdd(&s_hist[kps[3 * i + 2] & 255], 1u);
-            __syncthreads();
-            if (tid == 0) {
-                u32 acc = 0; int s = 255;
-                for (; s > 0; s--) { acc += s_hist[s]; if (acc >= (u32)(2 * quota)) break; }
-                s_val = (u32)s;
+            for (u32 i = tid; i < n1; i += 1024) {
+                const u32 k = skey[i];
+                if (hi == 32 || (k >> hi) == prefix) atomicAdd(&s_hist[(k >> sh) & ((1u << bits) - 1)], 1u);
             }
             __syncthreads();
-            smin = (int)s_val;
-            __syncthreads();
-        }
-    }
-    /* Harris response of the survivors */
-    u32 mine = 0;
-    for (int i = tid; i < n; i += 1024) {
-        u32 k = 0;
-        if (kps[3 * i + 2] >= smin) {
-            k = float_key(harris_response(ip, I.pitch, kps[3 * i], kps[3 * i + 1]));
-            mine++;
-        }
-        key[i] = k;
-    }
-    __syncthreads();
-    /* number of survivors */
-    s_scan[0][tid] = mine;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (tid < o) s_scan[0][tid] += s_scan[0][tid + o]; __syncthreads(); }
-    const u32 n1 = s_scan[0][0];
-    __syncthreads();
-    /* retainBest(quota) on the response: key of the quota-th largest, ties kept */
-    u32 T = 1; /* keep every survivor (keys are >= 1) */
-    if (n1 > (u32)quota) {
-        if (quota == 0) T = 0xFFFFFFFFu; /* nothing: real keys never reach this value... handled below */
-        else {
-            u32 prefix = 0, need = (u32)quota;
-            int hi = 32;
-            while (hi > 0) {
-                const int bits = hi >= 11 ? 11 : hi, sh = hi - bits;
-                for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
+            {   /* digit = largest d >= 1 with at least `need` keys of digit >= d (0 if none); thread t owns bins 2t, 2t+1 */
+                const u32 h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+                if (tid == 0) s_val = 0;
+                s_scan[tid] = h0 + h1;
                 __syncthreads();
-                for (int i = tid; i < n; i += 1024) {
-                    const u32 k = key[i];
-                    if (k && (hi == 32 || (k >> hi) == prefix)) atomicAdd(&s_hist[(k >> sh) & ((1u << bits) - 1)], 1u);
+                u32 S = h0 + h1; /* becomes the number of keys of digit >= 2 * tid */
+                for (int o = 1; o < 1024; o <<= 1) {
+                    const u32 t = tid + o < 1024 ? s_scan[tid + o] : 0u;
+                    __syncthreads();
+                    S += t;
+                    s_scan[tid] = S;
+                    __syncthreads();
                 }
-                __syncthreads();
-                if (tid == 0) {
-                    u32 acc = 0; int d = (1 << bits) - 1;
-                    for (; d > 0; d--) { if (acc + s_hist[d] >= need) break; acc += s_hist[d]; }
-                    s_val = (u32)d; s_hist[2048] = acc;
-                }
+                if (S - h0 >= need) atomicMax(&s_val, (u32)(2 * tid + 1));
+                else if (S >= need && tid > 0) atomicMax(&s_val, (u32)(2 * tid));
                 __syncthreads();
                 const u32 d = s_val;
-                need -= s_hist[2048];
-                prefix = (hi == 32 ? 0u : (prefix << bits)) | d;
-                hi = sh;
+                if ((d >> 1) == (u32)tid) s_hist[2048] = (d & 1) ? S - h0 - h1 : S - h0; /* keys of a larger digit */
                 __syncthreads();
             }
-            T = prefix;
+            const u32 d = s_val;
+            need -= s_hist[2048];
+            prefix = (hi == 32 ? 0u : (prefix << bits)) | d;
+            hi = sh;
+            __syncthreads();
         }
+        T = prefix;
     }
     u32 cnt = 0;
-    for (int i = tid; i < n; i += 1024) {
-        const u32 k = key[i];
-        const bool kp = (k != 0) && (quota > 0) && (k >= T);
-        keep[i] = kp ? 1 : 0;
-        cnt += kp ? 1u : 0u;
-    }
-    s_scan[0][tid] = cnt;
+    if (T != 0)
+        for (u32 i = tid; i < n1; i += 1024) cnt += skey[i] >= T ? 1u : 0u;
+    s_scan[tid] = cnt;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (tid < o) s_scan[0][tid] += s_scan[0][tid + o]; __syncthreads(); }
-    if (tid == 0) lvl_count[b * ORB_MAX_LEVELS + l] = (int)s_scan[0][0];
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) s_scan[tid] += s_scan[tid + o]; __syncthreads(); }
+    if (tid == 0) { lvl_count[b * ORB_MAX_LEVELS + l] = (int)s_scan[0]; L.thr[b * ORB_MAX_LEVELS + l] = T; }
 }
 
 __global__ __launch_bounds__(1024) void k_orb_emit(OrbLevels L, const int* __restrict__ lvl_count,
@@ -235,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_orb_emit(OrbLevels L, const int* __res
     const int n = min(L.cnt[l][b], cap);
     const int* kps = L.kps[l] + (size_t)b * cap * 3;
     const u32* key = L.key[l] + (size_t)b * cap;
-    const uint8_t* keep = L.keep[l] + (size_t)b * cap;
+    const u32 T = L.thr[b * ORB_MAX_LEVELS + l];
     int base = 0;
     for (int k = 0; k < l; k++) base += lvl_count[b * ORB_MAX_LEVELS + k];
     const float sf = L.scale[l];
@@ -243,7 +326,7 @@ __global__ __launch_bounds__(1024) void k_orb_emit(OrbLevels L, const int* __res
     const int per = (n + 1023) / 1024;
     const int i0 = min(tid * per, n), i1 = min(i0 + per, n);
     u32 mine = 0;
-    for (int i = i0; i < i1; i++) mine += keep[i];
+    for (int i = i0; i < i1; i++) mine += (T != 0 && key[i] >= T) ? 1u : 0u;
     int cur = 0;
     s_scan[0][tid] = mine;
     __syncthreads();
@@ -256,7 +339,7 @@ __global__ __launch_bounds__(1024) void k_orb_emit(OrbLevels L, const int* __res
     }
     int pos = base + (int)(s_scan[cur][tid] - mine);
     for (int i = i0; i < i1; i++) {
-        if (!keep[i]) continue;
+        if (T == 0 || key[i] < T) continue;
         if (pos < out_cap) {
             vfe_orb_kp kp;
             kp.lx = kps[3 * i]; kp.ly = kps[3 * i + 1];
@@ -376,8 +459,8 @@ struct OrbWs {
     int nlevels;
     int w[ORB_MAX_LEVELS], h[ORB_MAX_LEVELS], pitch[ORB_MAX_LEVELS], cap[ORB_MAX_LEVELS];
     size_t raw_off[ORB_MAX_LEVELS], blur_off[ORB_MAX_LEVELS], xtab_off[ORB_MAX_LEVELS], ytab_off[ORB_MAX_LEVELS];
-    size_t kps_off[ORB_MAX_LEVELS], cnt_off[ORB_MAX_LEVELS], key_off[ORB_MAX_LEVELS], keep_off[ORB_MAX_LEVELS];
-    size_t lvlcnt_off, fast_off, fast_bytes, total;
+    size_t kps_off[ORB_MAX_LEVELS], cnt_off[ORB_MAX_LEVELS], key_off[ORB_MAX_LEVELS], skey_off[ORB_MAX_LEVELS];
+    size_t lvlcnt_off, hist_off, hist_bytes, thr_off, fast_off, fast_bytes, total;
 };
 
 static int orb_layout(int width, int height, int batch, float scale_factor, int nlevels, OrbWs* L) {
@@ -399,9 +482,13 @@ static int orb_layout(int width, int height, int batch, float scale_factor, int 
         L->kps_off[l] = o; o += align_up((size_t)batch * L->cap[l] * 3 * sizeof(int), 256);
         L->cnt_off[l] = o; o += align_up((size_t)batch * sizeof(int), 256);
         L->key_off[l] = o; o += align_up((size_t)batch * L->cap[l] * sizeof(u32), 256);
-        L->keep_off[l] = o; o += align_up((size_t)batch * L->cap[l], 256);
+        L->skey_off[l] = o; o += align_up((size_t)batch * L->cap[l] * sizeof(u32), 256);
     }
     L->lvlcnt_off = o; o += align_up((size_t)batch * ORB_MAX_LEVELS * sizeof(int), 256);
+    /* score histograms and survivor counters, cleared together at the start of every call */
+    L->hist_bytes = align_up((size_t)batch * ORB_MAX_LEVELS * 257 * sizeof(u32), 256);
+    L->hist_off = o; o += L->hist_bytes;
+    L->thr_off = o; o += align_up((size_t)batch * ORB_MAX_LEVELS * sizeof(u32), 256);
     {   /* FAST runs on all levels at once (levels too small for the 31-pixel border yield nothing) */
         int fw[ORB_MAX_LEVELS], fh[ORB_MAX_LEVELS], nf = 0;
         for (int l = 0; l < nlevels; l++)
@@ -430,6 +517,7 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
     VFE_REQUIRE(kps && desc && counts && workspace && cap > 0, "NULL output or workspace");
     VFE_REQUIRE((uintptr_t)workspace % 256 == 0 && (uintptr_t)desc % 8 == 0, "workspace/desc alignment");
     VFE_REQUIRE(img->batch <= 65535, "batch too large");
+    VFE_REQUIRE(img->width <= 65535 && img->height <= 65535, "image too large");
     OrbWs W;
     if ((rc = orb_layout(img->width, img->height, img->batch, scale_factor, nlevels, &W))) return rc;
     if (workspace_bytes < W.total) {
@@ -457,17 +545,30 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
         L.kps[l] = (const int*)(ws + W.kps_off[l]);
         L.cnt[l] = (const int*)(ws + W.cnt_off[l]);
         L.key[l] = (u32*)(ws + W.key_off[l]);
-        L.keep[l] = (uint8_t*)(ws + W.keep_off[l]);
+        L.skey[l] = (u32*)(ws + W.skey_off[l]);
     }
     int* lvl_count = (int*)(ws + W.lvlcnt_off);
+    L.hist = (u32*)(ws + W.hist_off);
+    L.scnt = L.hist + (size_t)batch * ORB_MAX_LEVELS * 256;
+    L.thr = (u32*)(ws + W.thr_off);
     /* pyramid */
-    for (int l = 1; l < nlevels; l++) {
+    if (nlevels > 1) {
         ProfScope prof(VFE_K_ORB_RESIZE, st);
-        u32* xtab = (u32*)(ws + W.xtab_off[l]); u32* ytab = (u32*)(ws + W.ytab_off[l]);
-        hipLaunchKernelGGL(k_orb_tables, dim3(div_up(W.w[l], 256)), dim3(256), 0, st, W.w[l - 1], W.w[l], xtab);
-        hipLaunchKernelGGL(k_orb_tables, dim3(div_up(W.h[l], 256)), dim3(256), 0, st, W.h[l - 1], W.h[l], ytab);
-        hipLaunchKernelGGL(k_orb_resize, dim3(div_up(W.w[l], 256), W.h[l], batch), dim3(256), 0, st, L.raw[l - 1], L.raw[l], xtab, ytab);
+        OrbTabs T;
+        T.n = 0;
+        int maxd = 1;
+        for (int l = 1; l < nlevels; l++) {
+            T.ssize[T.n] = W.w[l - 1]; T.dsize[T.n] = W.w[l]; T.tab[T.n] = (u32*)(ws + W.xtab_off[l]); T.n++;
+            T.ssize[T.n] = W.h[l - 1]; T.dsize[T.n] = W.h[l]; T.tab[T.n] = (u32*)(ws + W.ytab_off[l]); T.n++;
+            maxd = W.w[l] > maxd ? W.w[l] : maxd; maxd = W.h[l] > maxd ? W.h[l] : maxd;
+        }
+        hipLaunchKernelGGL(k_orb_tables, dim3(div_up(maxd, 256), T.n), dim3(256), 0, st, T);
         VFE_LAUNCH_CHECK();
+        for (int l = 1; l < nlevels; l++) {
+            const u32* xtab = (const u32*)(ws + W.xtab_off[l]); const u32* ytab = (const u32*)(ws + W.ytab_off[l]);
+            hipLaunchKernelGGL(k_orb_resize, dim3(div_up(W.w[l], 256), W.h[l], batch), dim3(256), 0, st, L.raw[l - 1], L.raw[l], xtab, ytab);
+            VFE_LAUNCH_CHECK();
+        }
     }
     {   /* FAST on all levels at once (levels too small for the 31-pixel border yield nothing) */
         ProfScope prof(VFE_K_FAST, st);
@@ -485,14 +586,19 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
     }
     {
         ProfScope prof(VFE_K_ORB_SELECT, st);
-        hipLaunchKernelGGL(k_orb_select, dim3(nlevels, batch), dim3(1024), 0, st, L, lvl_count);
+        VFE_HIP(hipMemsetAsync(ws + W.hist_off, 0, W.hist_bytes, st));
+        hipLaunchKernelGGL(k_orb_hist, dim3(SEL_CHUNKS, nlevels, batch), dim3(256), 0, st, L);
+        VFE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_orb_harris, dim3(HARRIS_CHUNKS, nlevels, batch), dim3(64), 0, st, L);
+        VFE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_orb_thresh, dim3(nlevels, batch), dim3(1024), 0, st, L, lvl_count);
         VFE_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_orb_emit, dim3(nlevels, batch), dim3(1024), 0, st, L, lvl_count, kps, cap, counts);
         VFE_LAUNCH_CHECK();
     }
-    for (int l = 0; l < nlevels; l++) {
+    {
         ProfScope prof(VFE_K_ORB_BLUR, st);
-        if ((rc = orb_blur_launch(L.raw[l], L.blur[l], st))) return rc;
+        if ((rc = orb_blur_launch(L.raw, L.blur, nlevels, st))) return rc;
     }
     {
         ProfScope prof(VFE_K_ORB_DESC, st);

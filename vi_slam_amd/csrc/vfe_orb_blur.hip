@@ -7,7 +7,8 @@
  * down a band of rows.  Per source row a lane loads one dword, gets the three bytes it needs on either
  * side from its neighbours by shuffles, forms its four horizontal sums as two packed 16-bit pairs and
  * keeps the last seven rows of sums in a register ring; from the seventh row on every step emits one
- * output row.  The loop is unrolled seven times so that the ring slots are compile-time constants. */
+ * output row.  The loop is unrolled seven times so that the ring slots are compile-time constants.  One launch
+ * serves a set of images of different sizes (the levels of an ORB pyramid). */
 #include "vfe_common.h"
 #include <type_traits>
 
@@ -24,14 +25,30 @@ __device__ static inline u32 byte_pair(u32 lo, u32 hi, int i, int j) {
     return __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (u32)i | ((u32)j << 16));
 }
 
-template <bool ALIGNED>
-__global__ __launch_bounds__(256) void k_orb_blur(DImg src, DImg dst, int strips_x, int band_h, int bands_y, unsigned total_work) {
+#define GB_MAX_LEVELS 12
+struct BlurSet {
+    int n, band_h;
+    DImg src[GB_MAX_LEVELS], dst[GB_MAX_LEVELS];
+    int strips_x[GB_MAX_LEVELS], bands_y[GB_MAX_LEVELS], aligned[GB_MAX_LEVELS];
+    unsigned item_begin[GB_MAX_LEVELS + 1]; /* first (frame, band, strip) work item of an image */
+};
+
+__global__ __launch_bounds__(256) void k_orb_blur(BlurSet S) {
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
-    const int W = src.w, H = src.h;
-    const unsigned per_frame = (unsigned)(strips_x * bands_y);
+    const unsigned total_work = S.item_begin[S.n];
+    const int band_h = S.band_h;
     for (unsigned work = wave; work < total_work; work += nwaves) {
-        const int b = work / per_frame, t_item = work - (unsigned)b * per_frame;
+        int lv = 0;
+        while (lv + 1 < S.n && work >= S.item_begin[lv + 1]) lv++;
+        const DImg& src = S.src[lv];
+        DImg& dst = S.dst[lv];
+        const bool ALIGNED = S.aligned[lv] != 0;
+        const int strips_x = S.strips_x[lv];
+        const int W = src.w, H = src.h;
+        const unsigned per_frame = (unsigned)(strips_x * S.bands_y[lv]);
+        const unsigned item = work - S.item_begin[lv];
+        const int b = item / per_frame, t_item = item - (unsigned)b * per_frame;
         const int sxi = t_item % strips_x, byi = t_item / strips_x;
         const int X0 = sxi * GB_OUT + 4 * (lane - 1); /* image column of this lane's pixel 0 */
         const int y0 = byi * band_h, y1 = min(y0 + band_h, H);
@@ -118,17 +135,31 @@ __global__ __launch_bounds__(256) void k_orb_blur(DImg src, DImg dst, int strips
     }
 }
 
-int orb_blur_launch(const DImg& src, const DImg& dst, hipStream_t st) {
-    const int strips_x = div_up(src.w, GB_OUT);
+/* blurs n images of different sizes (same number of frames each) with one launch */
+int orb_blur_launch(const DImg* src, const DImg* dst, int n, hipStream_t st) {
+    if (n < 1 || n > GB_MAX_LEVELS) { vfe_set_error("blur: 1..%d images per launch", GB_MAX_LEVELS); return VFE_E_INVALID; }
+    BlurSet S;
+    S.n = n;
     int band_h = 64;
-    while (band_h > 16 && (long long)strips_x * div_up(src.h, band_h) * src.batch < 16384) band_h /= 2;
-    const int bands_y = div_up(src.h, band_h);
-    const unsigned total = (unsigned)(strips_x * bands_y * src.batch), nblk = (total + 3) / 4;
-    const bool aligned = ((uintptr_t)src.data % 4 == 0) && (src.pitch % 4 == 0) && (src.fstride % 4 == 0) &&
-                         ((uintptr_t)dst.data % 4 == 0) && (dst.pitch % 4 == 0) && (dst.fstride % 4 == 0) && src.sub_n == 1;
-    const dim3 grid(nblk < (1u << 20) ? nblk : (1u << 20));
-    if (aligned) hipLaunchKernelGGL(k_orb_blur<true>, grid, dim3(256), 0, st, src, dst, strips_x, band_h, bands_y, total);
-    else hipLaunchKernelGGL(k_orb_blur<false>, grid, dim3(256), 0, st, src, dst, strips_x, band_h, bands_y, total);
+    for (; band_h > 16; band_h /= 2) {
+        long long items = 0;
+        for (int l = 0; l < n; l++) items += (long long)div_up(src[l].w, GB_OUT) * div_up(src[l].h, band_h) * src[l].batch;
+        if (items >= 16384) break;
+    }
+    S.band_h = band_h;
+    unsigned long long items = 0;
+    for (int l = 0; l < n; l++) {
+        S.src[l] = src[l]; S.dst[l] = dst[l];
+        S.strips_x[l] = div_up(src[l].w, GB_OUT); S.bands_y[l] = div_up(src[l].h, band_h);
+        S.aligned[l] = ((uintptr_t)src[l].data % 4 == 0) && (src[l].pitch % 4 == 0) && (src[l].fstride % 4 == 0) &&
+                       ((uintptr_t)dst[l].data % 4 == 0) && (dst[l].pitch % 4 == 0) && (dst[l].fstride % 4 == 0) && src[l].sub_n == 1;
+        S.item_begin[l] = (unsigned)items;
+        items += (unsigned long long)S.strips_x[l] * S.bands_y[l] * src[l].batch;
+    }
+    if (items >= (1ull << 31)) { vfe_set_error("blur: image set too large"); return VFE_E_INVALID; }
+    S.item_begin[n] = (unsigned)items;
+    const unsigned nblk = ((unsigned)items + 3) / 4;
+    hipLaunchKernelGGL(k_orb_blur, dim3(nblk < (1u << 20) ? nblk : (1u << 20)), dim3(256), 0, st, S);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
