@@ -32,7 +32,11 @@ typedef unsigned long long u64;
 __constant__ signed char c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+/* half-width of the circular patch at row |v| */
+__host__ __device__ constexpr int orb_umax(int v) {
+    constexpr int t[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    return t[v];
+}
 
 /* ---- level geometry (host; same expressions as OpenCV's ORB) ------------------------------ */
 static float orb_scale(int level, float scale_factor) { return (float)pow((double)scale_factor, (double)level); }
@@ -83,19 +87,46 @@ __global__ void k_orb_tables(OrbTabs T) {
     T.tab[e][v] = (ofs << 9) | w1;
 }
 
-__global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    if (x >= dst.w) return;
-    const u32 ty = ytab[y], tx = xtab[x];
-    const int yo = ty >> 9, xo = tx >> 9;
-    const u32 wy1 = ty & 511, wy0 = 256 - wy1, wx1 = tx & 511, wx0 = 256 - wx1;
+/* four horizontally adjacent output pixels per thread: 16 independent source loads in flight instead of 4.
+ * xtab holds at least 4 * w4 entries (those past dst.w are not read as offsets). */
+__global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab,
+                                                    int w4, unsigned per_frame) {
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    const int b = blockIdx.y;
+    if (id >= per_frame) return;
+    const int y = id / (unsigned)w4, x = 4 * (int)(id - (unsigned)y * (unsigned)w4);
+    uint4 t4 = *reinterpret_cast<const uint4*>(xtab + x);
+    if (x + 1 >= dst.w) t4.y = 0;
+    if (x + 2 >= dst.w) t4.z = 0;
+    if (x + 3 >= dst.w) t4.w = 0;
+    const u32 tx[4] = {t4.x, t4.y, t4.z, t4.w};
+    const u32 ty = ytab[y];
+    const int yo = ty >> 9;
+    const u32 wy1 = ty & 511, wy0 = 256 - wy1;
     const uint8_t* r0 = src.frame(b) + (size_t)yo * src.pitch;
     const uint8_t* r1 = src.frame(b) + (size_t)min(yo + 1, src.h - 1) * src.pitch;
-    const int x1 = min(xo + 1, src.w - 1);
-    const u32 h0 = r0[xo] * wx0 + r0[x1] * wx1;
-    const u32 h1 = r1[xo] * wx0 + r1[x1] * wx1;
-    const u32 v = h0 * wy0 + h1 * wy1;
-    dst.frame(b)[(size_t)y * dst.pitch + x] = (uint8_t)((v + (1u << 15)) >> 16);
+    u32 p[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int xo = tx[k] >> 9, x1 = min(xo + 1, src.w - 1);
+        p[k][0] = r0[xo]; p[k][1] = r0[x1]; p[k][2] = r1[xo]; p[k][3] = r1[x1];
+    }
+    u32 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 wx1 = tx[k] & 511, wx0 = 256 - wx1;
+        const u32 h0 = p[k][0] * wx0 + p[k][1] * wx1;
+        const u32 h1 = p[k][2] * wx0 + p[k][3] * wx1;
+        o[k] = ((h0 * wy0 + h1 * wy1) + (1u << 15)) >> 16;
+    }
+    uint8_t* op = dst.frame(b) + (size_t)y * dst.pitch + x;
+    if (x + 3 < dst.w && ((dst.pitch | dst.fstride | (size_t)(uintptr_t)dst.data) & 3) == 0)
+        *reinterpret_cast<u32*>(op) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+    else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (x + k < dst.w) op[k] = (uint8_t)o[k];
+    }
 }
 
 /* 7x7 Gaussian, sigma 2 (vfe_orb_blur.hip) */
@@ -415,14 +446,26 @@ __global__ __launch_bounds__(256) void k_orb_desc(OrbLevels L, vfe_orb_kp* __res
         const int l = kp->octave, px = kp->lx, py = kp->ly;
         const DImg& I = L.raw[l];
         const uint8_t* ip = I.frame(b);
-        /* intensity centroid over the circular patch: lane <-> column u, loop over rows v */
+        /* intensity centroid over the circular patch: lane & 31 <-> column u; lanes 0..31 take rows -15 .. 0,
+         * lanes 32..63 rows 1 .. 15 (row 16 - j of the lower half pairs with row j - 15 of the upper: same
+         * half-width).  All loads are issued before the first use. */
         int m10 = 0, m01 = 0;
-        const int u = lane - ORB_HALF;
-        for (int v = -ORB_HALF; v <= ORB_HALF; v++) {
-            const int d = c_umax[v < 0 ? -v : v];
-            if (lane < ORB_PATCH && u >= -d && u <= d) {
-                const int val = ip[(size_t)(py + v) * I.pitch + px + u];
-                m10 += u * val; m01 += v * val;
+        {
+            const int u = (lane & 31) - ORB_HALF;
+            const bool low = lane >= 32;
+            const uint8_t* col = ip + (size_t)py * I.pitch + px + u;
+            int val[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int d = orb_umax(15 - j);              /* |v| = 15 - j in both halves ... */
+                const int v = low ? 15 - j : j - 15;         /* ... v = -(15 - j) above, 15 - j below */
+                const bool on = (lane & 31) < ORB_PATCH && u >= -d && u <= d && !(low && j == 15);
+                val[j] = on ? (int)col[(ptrdiff_t)v * I.pitch] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int v = low ? 15 - j : j - 15;
+                m10 += u * val[j]; m01 += v * val[j];
             }
         }
 #pragma unroll
@@ -566,7 +609,9 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
         VFE_LAUNCH_CHECK();
         for (int l = 1; l < nlevels; l++) {
             const u32* xtab = (const u32*)(ws + W.xtab_off[l]); const u32* ytab = (const u32*)(ws + W.ytab_off[l]);
-            hipLaunchKernelGGL(k_orb_resize, dim3(div_up(W.w[l], 256), W.h[l], batch), dim3(256), 0, st, L.raw[l - 1], L.raw[l], xtab, ytab);
+            const int w4 = div_up(W.w[l], 4);
+            const unsigned per_frame = (unsigned)w4 * (unsigned)W.h[l];
+            hipLaunchKernelGGL(k_orb_resize, dim3((per_frame + 255) / 256, batch), dim3(256), 0, st, L.raw[l - 1], L.raw[l], xtab, ytab, w4, per_frame);
             VFE_LAUNCH_CHECK();
         }
     }
