@@ -94,6 +94,15 @@ int vfe_dev_bgr2gray(const vfe_dimg* bgr, const vfe_dimg* gray, void* stream);
 size_t vfe_equalize_workspace(int batch);
 int vfe_dev_equalize_hist(const vfe_dimg* src, const vfe_dimg* dst, void* workspace, size_t workspace_bytes, void* stream);
 
+/* cv::createCLAHE(clip_limit, Size(tiles_x, tiles_y))->apply on 8-bit gray frames (`histogram_method: "CLAHE"`,
+ * reference docs/reference/15_openvins_smartphone_config.md:111; OpenVINS uses clip 10.0 on 8 x 8 tiles).
+ * Sizes that are not multiples of the tile grid are extended by reflection for the histograms, as
+ * OpenCV does.  dst may be the same image.  1..64 tiles per dimension.
+ * workspace: vfe_clahe_workspace(batch, tiles_x, tiles_y) bytes, 256-byte aligned. */
+size_t vfe_clahe_workspace(int batch, int tiles_x, int tiles_y);
+int vfe_dev_clahe(const vfe_dimg* src, const vfe_dimg* dst, double clip_limit, int tiles_x, int tiles_y,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- pyramids -------------------------------------------------------------------------- */
 
 /* cv::pyrDown: dst must be ((w+1)/2) x ((h+1)/2), same batch.  The stage the reference's
@@ -300,10 +309,14 @@ int vfe_create(const vfe_config* cfg, vfe_ctx** out);
 void vfe_destroy(vfe_ctx* ctx);
 /* forget the previous frame and all tracks (ISLAMFramework::reset, i_slam_framework.hpp:103) */
 int vfe_reset(vfe_ctx* ctx);
-/* When enabled, every frame handed to the calls below is histogram-equalised (cv::equalizeHist) on
- * the GPU after upload / BGR conversion and before anything else reads it: `equalize: 1` of
- * reference config/vins_mono.yaml:104.  Off by default. */
-int vfe_set_equalize(vfe_ctx* ctx, int enable);
+/* Every frame handed to the calls below is equalised on the GPU after upload / BGR conversion and before
+ * anything else reads it.  mode VFE_EQ_HIST: cv::equalizeHist (`equalize: 1` of reference
+ * config/vins_mono.yaml:104); VFE_EQ_CLAHE: CLAHE with clip 10.0 on 8 x 8 tiles (`histogram_method: "CLAHE"`,
+ * reference docs/reference/15_openvins_smartphone_config.md:111); VFE_EQ_NONE (default): off. */
+#define VFE_EQ_NONE 0
+#define VFE_EQ_HIST 1
+#define VFE_EQ_CLAHE 2
+int vfe_set_equalize(vfe_ctx* ctx, int mode);
 
 /* goodFeaturesToTrack on a host image (channels 1 or 3; 3 = BGR, converted on the GPU). */
 int vfe_detect_shi_tomasi(vfe_ctx* ctx, const uint8_t* data, int rows, int cols, size_t step, int channels,

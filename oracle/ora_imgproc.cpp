@@ -44,6 +44,73 @@ extern "C" void ora_equalize_hist(const uint8_t* src, int w, int h, int step, ui
         for (int x = 0; x < w; x++) dst[(size_t)y * dstep + x] = lut[src[(size_t)y * step + x]];
 }
 
+/* CLAHE (cv::createCLAHE(clipLimit, Size(tilesX, tilesY))->apply) on 8-bit gray, as OpenVINS-style front-ends
+ * use it (`histogram_method: "CLAHE"`, docs/reference/15_openvins_smartphone_config.md:111).
+ *   - if either dimension is not a multiple of the tile count the image is extended at the right/bottom by
+ *     tiles - (size % tiles) pixels in BOTH dimensions (a dimension that divides evenly gets a full `tiles`
+ *     extra) with reflect-101, for the histograms only;
+ *   - per tile: histogram, clip at max(int(clip * area / 256), 1), spread the excess (equal share to every bin,
+ *     the remainder one count to every `256 / remainder`-th bin from bin 0), LUT = saturate(round(cdf * 255 / area));
+ *   - every pixel: bilinear blend of the four surrounding tiles' LUT entries in float, tile centres at
+ *     (t + 0.5) * tile size, rounded half-to-even. */
+extern "C" int ora_clahe(const uint8_t* src, int w, int h, int step, uint8_t* dst, int dstep, double clip, int tiles_x,
+                         int tiles_y) {
+    if (tiles_x < 1 || tiles_y < 1 || w < 1 || h < 1) return -1;
+    int ew = w, eh = h;
+    if (w % tiles_x != 0 || h % tiles_y != 0) { ew = w + tiles_x - (w % tiles_x); eh = h + tiles_y - (h % tiles_y); }
+    if (ew - w >= w || eh - h >= h) return -1; /* reflect-101 needs the extension to be smaller than the image */
+    const int tw = ew / tiles_x, th = eh / tiles_y, area = tw * th;
+    const float lut_scale = (float)(256 - 1) / (float)area;
+    int clip_limit = 0;
+    if (clip > 0.0) { clip_limit = (int)(clip * area / 256); clip_limit = std::max(clip_limit, 1); }
+    std::vector<uint8_t> lut((size_t)tiles_x * tiles_y * 256);
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            int hist[256] = {0};
+            for (int y = ty * th; y < (ty + 1) * th; y++)
+                for (int x = tx * tw; x < (tx + 1) * tw; x++) hist[src[(size_t)reflect101(y, h) * step + reflect101(x, w)]]++;
+            if (clip_limit > 0) {
+                int clipped = 0;
+                for (int i = 0; i < 256; i++)
+                    if (hist[i] > clip_limit) { clipped += hist[i] - clip_limit; hist[i] = clip_limit; }
+                const int batch = clipped / 256;
+                int residual = clipped - batch * 256;
+                for (int i = 0; i < 256; i++) hist[i] += batch;
+                if (residual != 0) {
+                    const int rstep = std::max(256 / residual, 1);
+                    for (int i = 0; i < 256 && residual > 0; i += rstep, residual--) hist[i]++;
+                }
+            }
+            uint8_t* L = &lut[((size_t)ty * tiles_x + tx) * 256];
+            int sum = 0;
+            for (int i = 0; i < 256; i++) {
+                sum += hist[i];
+                const int v = cv_roundf((float)sum * lut_scale);
+                L[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+        }
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    for (int y = 0; y < h; y++) {
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = cv_floorf(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        ty1 = std::max(ty1, 0); ty2 = std::min(ty2, tiles_y - 1);
+        for (int x = 0; x < w; x++) {
+            const float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = cv_floorf(txf), tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            tx1 = std::max(tx1, 0); tx2 = std::min(tx2, tiles_x - 1);
+            const int v = src[(size_t)y * step + x];
+            const float p11 = lut[((size_t)ty1 * tiles_x + tx1) * 256 + v], p12 = lut[((size_t)ty1 * tiles_x + tx2) * 256 + v];
+            const float p21 = lut[((size_t)ty2 * tiles_x + tx1) * 256 + v], p22 = lut[((size_t)ty2 * tiles_x + tx2) * 256 + v];
+            const float res = (p11 * xa1 + p12 * xa) * ya1 + (p21 * xa1 + p22 * xa) * ya;
+            const int r = cv_roundf(res);
+            dst[(size_t)y * dstep + x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+    }
+    return 0;
+}
+
 /* pyrDown: separable [1 4 6 4 1] on source samples 2x-2..2x+2 (reflect-101),
  * integer accumulation, one rounding: (sum + 128) >> 8. */
 extern "C" void ora_pyr_down(const uint8_t* src, int w, int h, int step, uint8_t* dst, int dstep) {

@@ -67,6 +67,17 @@ def equalize_hist(img):
     return out
 
 
+def clahe(img, clip_limit=10.0, tiles_x=8, tiles_y=8):
+    img, p = _u8(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.uint8)
+    L = lib()
+    L.ora_clahe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int]
+    if L.ora_clahe(p, w, h, w, _p(out, C.c_uint8), w, float(clip_limit), tiles_x, tiles_y) != 0:
+        raise ValueError("ora_clahe: bad tile grid")
+    return out
+
+
 def pyr_down(img):
     img, p = _u8(img)
     h, w = img.shape

@@ -16,6 +16,8 @@ void ora_bgr2gray(const uint8_t* bgr, int w, int h, int step, uint8_t* gray, int
 
 /* equalizeHist on 8-bit gray (config/vins_mono.yaml:104 `equalize`). */
 void ora_equalize_hist(const uint8_t* src, int w, int h, int step, uint8_t* dst, int dstep);
+/* CLAHE (`histogram_method: "CLAHE"`, docs/reference/15_openvins_smartphone_config.md:111); 0 on success. */
+int ora_clahe(const uint8_t* src, int w, int h, int step, uint8_t* dst, int dstep, double clip, int tiles_x, int tiles_y);
 
 /* pyrDown: dst is ((w+1)/2) x ((h+1)/2). */
 void ora_pyr_down(const uint8_t* src, int w, int h, int step, uint8_t* dst, int dstep);

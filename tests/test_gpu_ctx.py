@@ -75,6 +75,45 @@ def test_ctx_equalize_flag(ctx):
     assert np.array_equal(ctx.detect_shi_tomasi(im, 150, 0.01, 30), plain)
 
 
+@pytest.mark.parametrize("w,h,clip,tx,ty", [(752, 480, 10.0, 8, 8), (750, 477, 10.0, 8, 8), (1920, 1080, 10.0, 8, 8),
+                                            (641, 481, 2.0, 4, 6), (320, 240, 0.0, 8, 8), (203, 99, 40.0, 3, 2),
+                                            (752, 480, 3.0, 32, 30)])
+def test_clahe_bit_exact(cuda, w, h, clip, tx, ty):
+    """cv::CLAHE (`histogram_method: "CLAHE"`): sizes that divide the tile grid and sizes that need the reflected
+    extension, no clipping, tiny tiles; a low-contrast scene, noise and a constant frame."""
+    import torch
+    imgs = [(synth.scene(synth.BASE_SEED + 32, w, h, 0) // 4 + 60).astype(np.uint8), synth.noise(11, w, h),
+            np.full((h, w), 77, np.uint8), synth.scene(synth.BASE_SEED + 33, w, h, 0)]
+    t = capi.alloc_image(len(imgs), h, w, cuda)
+    t.copy_(torch.from_numpy(np.stack(imgs)).to(cuda))
+    out = capi.clahe(t, clip, tx, ty).cpu().numpy()
+    for i, im in enumerate(imgs):
+        assert np.array_equal(out[i], ora.clahe(im, clip, tx, ty)), f"frame {i}"
+    # in place, unaligned rows
+    u = torch.empty((1, h, w + 3), dtype=torch.uint8, device=cuda)[:, :, 1:w + 1]
+    u.copy_(torch.from_numpy(imgs[3][None]).to(cuda))
+    capi.clahe(u, clip, tx, ty, out=u)
+    assert np.array_equal(u[0].cpu().numpy(), ora.clahe(imgs[3], clip, tx, ty))
+
+
+def test_clahe_rejects_bad_grids(cuda):
+    t = capi.alloc_image(1, 64, 64, cuda)
+    for tx, ty in [(0, 8), (8, 65), (64, 64)]:
+        with pytest.raises(capi.VfeError):
+            capi.clahe(t, 10.0, tx, ty)
+
+
+def test_ctx_clahe_mode(ctx):
+    im = (synth.scene(synth.BASE_SEED + 34, 752, 480, 0) // 3 + 40).astype(np.uint8)
+    ctx.set_equalize("clahe")
+    try:
+        got = ctx.detect_shi_tomasi(im, 150, 0.01, 30)
+    finally:
+        ctx.set_equalize(False)
+    ref, _ = ora.good_features(ora.clahe(im, 10.0, 8, 8), 150, 0.01, 30)
+    assert len(ref) > 20 and np.array_equal(got, ref)
+
+
 def test_ctx_klt(ctx):
     w, h = 752, 480
     a, b = synth.scene(synth.BASE_SEED + 22, w, h, 0), synth.scene(synth.BASE_SEED + 22, w, h, 1)

@@ -201,6 +201,30 @@ def test_equalize_hist_spreads_range(img):
     assert e.min() == 0 and e.max() == 255
 
 
+def test_clahe_single_tile_without_clipping_is_the_plain_cdf_map(img):
+    """One tile and no clip limit: every pixel maps through round(cdf(v) * 255 / area), with no blending."""
+    e = ora.clahe(img, 0.0, 1, 1)
+    hist = np.bincount(img.ravel(), minlength=256)
+    lut = np.rint(np.cumsum(hist).astype(np.float32) * (np.float32(255) / np.float32(img.size))).clip(0, 255).astype(np.uint8)
+    assert np.array_equal(e, lut[img])
+    # a clip limit no bin reaches changes nothing
+    assert np.array_equal(ora.clahe(img, 256.0, 1, 1), e)
+
+
+def test_clahe_limits_contrast_gain(img):
+    """A low-contrast frame is stretched, the less so the lower the clip limit; a constant frame stays constant."""
+    low = (img // 8 + 100).astype(np.uint8)
+    s10, s2 = ora.clahe(low, 10.0, 8, 8).std(), ora.clahe(low, 2.0, 8, 8).std()
+    assert s10 > s2 > low.std()
+    c = ora.clahe(np.full(img.shape, 77, np.uint8), 10.0, 8, 8)
+    assert c.min() == c.max()
+    # sizes that do not divide the grid are handled (reflected extension for the histograms)
+    h, w = img.shape
+    assert ora.clahe(img[:h - 3, :w - 5], 10.0, 8, 8).shape == (h - 3, w - 5)
+    with pytest.raises(ValueError):
+        ora.clahe(img[:4, :4], 10.0, 8, 8)
+
+
 def test_undistort_points_inverts_the_radtan_model():
     """Distort normalised points with the plumb-bob model, project, undistort: the fixed-point iteration
     recovers them (tightly near the principal point, where five iterations suffice)."""

@@ -96,6 +96,8 @@ SIGNATURES = {
     "vfe_set_equalize": (C.c_int, [_P, C.c_int]),
     "vfe_equalize_workspace": (C.c_size_t, [C.c_int]),
     "vfe_dev_equalize_hist": (C.c_int, [_DI, _DI, _P, C.c_size_t, _P]),
+    "vfe_clahe_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "vfe_dev_clahe": (C.c_int, [_DI, _DI, C.c_double, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "vfe_detect_shi_tomasi": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_double,
                                         C.c_double, _P, C.POINTER(C.c_int)]),
     "vfe_klt_track": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int,
@@ -438,6 +440,18 @@ def equalize_hist(img, out=None):
     return out
 
 
+def clahe(img, clip_limit=10.0, tiles_x=8, tiles_y=8, out=None):
+    """cv::createCLAHE(clip_limit, (tiles_x, tiles_y)).apply on a [B, H, W] uint8 cuda batch (in place when out is img)."""
+    import torch
+    if out is None:
+        out = alloc_image(img.shape[0], img.shape[1], img.shape[2], img.device)
+    nbytes = lib().vfe_clahe_workspace(img.shape[0], tiles_x, tiles_y)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=img.device)
+    check(lib().vfe_dev_clahe(C.byref(dimg(img)), C.byref(dimg(out)), float(clip_limit), tiles_x, tiles_y, _ptr(ws), nbytes,
+                              _stream()))
+    return out
+
+
 def fast_grid(img, threshold, grid_x, grid_y, num_features, min_px_dist, seeds=None, n_seeds=None):
     """(pts [B, cap, 2] float32, scores [B, cap] int32, counts [B])."""
     import torch
@@ -483,8 +497,10 @@ class Context:
     def reset(self):
         check(lib().vfe_reset(self._h))
 
-    def set_equalize(self, on):
-        check(lib().vfe_set_equalize(self._h, 1 if on else 0))
+    def set_equalize(self, mode):
+        """False/0 off, True/1 cv::equalizeHist, 2 or "clahe" CLAHE (clip 10, 8 x 8 tiles)."""
+        m = 2 if mode == "clahe" else int(mode)
+        check(lib().vfe_set_equalize(self._h, m))
 
     def detect_shi_tomasi(self, img, max_corners, quality, min_distance):
         a, p, rows, cols, step, ch = self._img(img)

@@ -85,7 +85,9 @@ static int ctx_upload(vfe_ctx* c, int slot, const uint8_t* data, int rows, int c
     }
     if (c->equalize) {
         vfe_dimg g = ctx_level(c, slot, 0, cols, rows);
-        int rc = vfe_dev_equalize_hist(&g, &g, c->eq_hist, vfe_equalize_workspace(1), c->stream);
+        int rc = c->equalize == VFE_EQ_CLAHE
+                     ? vfe_dev_clahe(&g, &g, 10.0, 8, 8, c->eq_hist, vfe_clahe_workspace(1, 8, 8), c->stream)
+                     : vfe_dev_equalize_hist(&g, &g, c->eq_hist, vfe_equalize_workspace(1), c->stream);
         if (rc) return rc;
     }
     return VFE_OK;
@@ -143,7 +145,10 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
     }
     const size_t N = (size_t)cfg->max_features;
     CTX_TRY(hipMalloc((void**)&c->bgr, (size_t)cfg->max_width * 3 * cfg->max_height));
-    CTX_TRY(hipMalloc((void**)&c->eq_hist, vfe_equalize_workspace(1)));
+    {
+        const size_t a = vfe_equalize_workspace(1), b = vfe_clahe_workspace(1, 8, 8);
+        CTX_TRY(hipMalloc((void**)&c->eq_hist, a > b ? a : b));
+    }
     CTX_TRY(hipMalloc((void**)&c->pts, N * 2 * sizeof(float)));
     CTX_TRY(hipMalloc((void**)&c->next_pts, N * 2 * sizeof(float)));
     CTX_TRY(hipMalloc((void**)&c->corners, N * 2 * sizeof(float)));
@@ -179,7 +184,8 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
 
 extern "C" int vfe_set_equalize(vfe_ctx* c, int enable) {
     VFE_REQUIRE(c, "ctx is NULL");
-    c->equalize = enable ? 1 : 0;
+    VFE_REQUIRE(enable == VFE_EQ_NONE || enable == VFE_EQ_HIST || enable == VFE_EQ_CLAHE, "mode must be 0, 1 or 2");
+    c->equalize = enable;
     return VFE_OK;
 }
 
