@@ -167,6 +167,12 @@ int vfe_dev_klt_track_bidir(const vfe_dimg* prev_levels, const vfe_dimg* next_le
                             int win, int max_iter, double eps, double min_eig_thr, double max_recovered_dist2,
                             void* stream);
 
+/* cv::cornerSubPix(img, pts, Size(win, win), Size(zero_zone, zero_zone), {COUNT+EPS, max_iter, eps}) on every
+ * frame's points, in place (`subpixel: true`, reference config/basalt.yaml:102).  win = half window (1..10),
+ * zero_zone < 0 = none.  pts [batch][pts_cap][2]; n_pts [batch] (device; NULL = pts_cap points per frame). */
+int vfe_dev_corner_subpix(const vfe_dimg* img, float* pts, const int* n_pts, int pts_cap, int win, int zero_zone,
+                          int max_iter, double eps, void* stream);
+
 /* cv::undistortPoints (no R, no P): pixel positions -> normalised, undistorted coordinates for the
  * radial-tangential model the configs carry (`camera.k1, k2, p1, p2`, reference
  * config/vins_mono.yaml:32-35).  camera4 = {fx, fy, cx, cy}, dist5 = {k1, k2, p1, p2, k3} (host

@@ -192,6 +192,18 @@ def undistort_points(pts, camera, dist):
     return out
 
 
+def corner_subpix(img, pts, win=5, zero_zone=-1, max_iter=30, eps=0.01):
+    img, ip = _u8(img)
+    h, w = img.shape
+    p = np.array(pts, np.float32).reshape(-1, 2).copy()
+    L = lib()
+    L.ora_corner_subpix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_double]
+    if L.ora_corner_subpix(ip, w, h, w, _p(p, C.c_float), len(p), win, zero_zone, max_iter, float(eps)) != 0:
+        raise ValueError("ora_corner_subpix: bad parameters")
+    return p
+
+
 def fast9(img, threshold, nms=True):
     img, p = _u8(img)
     h, w = img.shape

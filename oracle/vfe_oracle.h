@@ -96,6 +96,12 @@ void ora_match_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt,
  * (float)d0 < ratio * (float)d1. */
 void ora_ratio_test(const int* idx, const int* dist, int nq, float ratio, uint8_t* good);
 
+/* cv::cornerSubPix (`subpixel: true`, config/basalt.yaml:102); pts [n][2] refined in place; 0 on success.
+ * ora_subpix_mask fills the (2*win+1)^2 window weights. */
+int ora_subpix_mask(int win, int zero_zone, float* mask);
+int ora_corner_subpix(const uint8_t* img, int w, int h, int step, float* pts, int n, int win, int zero_zone,
+                      int max_iter, double eps);
+
 #ifdef __cplusplus
 }
 #endif

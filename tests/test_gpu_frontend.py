@@ -237,6 +237,38 @@ def test_undistort_points_bit_exact(cuda):
     assert centre.sum() > 500 and ex[centre].max() < 0.01 and ey[centre].max() < 0.01
 
 
+@pytest.mark.parametrize("win,zero_zone,max_iter,eps", [(5, -1, 30, 0.01), (3, -1, 40, 0.001), (10, 1, 5, 0.03), (1, -1, 1, 0.0)])
+def test_corner_subpix_bit_exact(cuda, win, zero_zone, max_iter, eps):
+    """cv::cornerSubPix (`subpixel: true`, config/basalt.yaml:102) on detected corners, points near the rim and
+    points on flat ground (singular system): bit-exact positions, ragged per-frame counts."""
+    import torch
+    w, h = 752, 480
+    imgs = [synth.scene(synth.BASE_SEED + 40 + i, w, h, 0) for i in range(3)]
+    imgs[2] = np.full((h, w), 90, np.uint8)
+    cap = 300
+    pts = np.zeros((3, cap, 2), np.float32)
+    n = np.zeros(3, np.int32)
+    for b in range(2):
+        c, _ = ora.good_features(imgs[b], 250, 0.01, 10)
+        extra = np.array([[0, 0], [w - 1, h - 1], [1.5, 200.25], [w - 2.25, 3.5], [400.5, 0.75]], np.float32)
+        c = np.concatenate([c.astype(np.float32) + np.float32(0.25) * (b == 1), extra])
+        pts[b, :len(c)] = c; n[b] = len(c)
+    pts[2, :10] = [[100 + 7 * i, 50 + 3 * i] for i in range(10)]; n[2] = 10
+    t = capi.alloc_image(3, h, w, cuda)
+    t.copy_(torch.from_numpy(np.stack(imgs)).to(cuda))
+    d_pts = torch.from_numpy(pts).to(cuda)
+    capi.corner_subpix(t, d_pts, torch.from_numpy(n).to(cuda), win, zero_zone, max_iter, eps)
+    got = d_pts.cpu().numpy()
+    moved = 0
+    for b in range(3):
+        ref = ora.corner_subpix(imgs[b], pts[b, :n[b]], win, zero_zone, max_iter, eps)
+        assert np.array_equal(got[b, :n[b]].view(np.uint32), ref.view(np.uint32)), f"frame {b}"
+        assert np.array_equal(got[b, n[b]:], pts[b, n[b]:]), "points past the count were touched"
+        moved += int((ref != pts[b, :n[b]]).any(axis=1).sum())
+    assert np.array_equal(got[2, :10], pts[2, :10]), "flat ground: singular system leaves the point alone"
+    assert moved > 200
+
+
 def _oracle_step(prev, cur, pts, n, q, d, levels, w, h):
     nxt, st, _ = ora.klt_track(prev, cur, pts, 21, levels - 1)
     r = np.rint(nxt)

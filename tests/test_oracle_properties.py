@@ -225,6 +225,25 @@ def test_clahe_limits_contrast_gain(img):
         ora.clahe(img[:4, :4], 10.0, 8, 8)
 
 
+def test_corner_subpix_finds_an_analytic_corner():
+    """An X-corner rendered by 8x8 area sampling at a known sub-pixel position: refinement from a start two pixels
+    off lands within 0.15 px (exactly on it when the corner is symmetric about a pixel boundary)."""
+    def quadrant(w, h, cx, cy, ss=8):
+        ys = (np.arange(h * ss) + 0.5) / ss
+        xs = (np.arange(w * ss) + 0.5) / ss
+        X, Y = np.meshgrid(xs, ys)
+        hi = ((X < cx) & (Y < cy)) | ((X >= cx) & (Y >= cy))
+        return np.rint(np.where(hi, 200.0, 50.0).reshape(h, ss, w, ss).mean(axis=(1, 3))).astype(np.uint8)
+    for cx, cy, tol in [(32.3, 30.7, 0.15), (31.5, 31.5, 0.001), (40.25, 20.8, 0.15)]:
+        im = quadrant(64, 64, cx, cy)
+        start = np.array([[round(cx - 0.5) + 1.0, round(cy - 0.5) - 1.0]], np.float32)
+        r = ora.corner_subpix(im, start, 5, -1, 40, 0.001)[0]
+        assert abs(r[0] - (cx - 0.5)) < tol and abs(r[1] - (cy - 0.5)) < tol
+    # flat image: the normal equations are singular, the point stays
+    flat = np.full((64, 64), 80, np.uint8)
+    assert np.array_equal(ora.corner_subpix(flat, [[20.5, 30.25]]), np.array([[20.5, 30.25]], np.float32))
+
+
 def test_undistort_points_inverts_the_radtan_model():
     """Distort normalised points with the plumb-bob model, project, undistort: the fixed-point iteration
     recovers them (tightly near the principal point, where five iterations suffice)."""

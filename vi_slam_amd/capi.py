@@ -67,6 +67,7 @@ SIGNATURES = {
     "vfe_dev_klt_track_bidir": (C.c_int, [_DI, _DI, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                           C.c_double, C.c_double, C.c_double, _P]),
     "vfe_dev_undistort_points": (C.c_int, [_P, _P, C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
+    "vfe_dev_corner_subpix": (C.c_int, [_DI, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P]),
     "vfe_dev_compact_tracks": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "vfe_dev_append_points": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "vfe_frontend_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -274,6 +275,15 @@ def undistort_points(pts, camera, dist):
     d5 = (C.c_double * 5)(*dist)
     check(lib().vfe_dev_undistort_points(_ptr(pts.contiguous()), _ptr(out), pts.numel() // 2, cam, d5, _stream()))
     return out
+
+
+def corner_subpix(img, pts, n_pts=None, win=5, zero_zone=-1, max_iter=30, eps=0.01):
+    """cv::cornerSubPix on a [B, H, W] uint8 cuda batch; pts [B, cap, 2] float32 cuda, refined in place."""
+    b, cap, _ = pts.shape
+    assert pts.is_contiguous() and b == img.shape[0]
+    check(lib().vfe_dev_corner_subpix(C.byref(dimg(img)), _ptr(pts), _ptr(n_pts) if n_pts is not None else None, cap, win,
+                                      zero_zone, max_iter, float(eps), _stream()))
+    return pts
 
 
 def compact_tracks(pts, status, n_pts, width, height, border=1):

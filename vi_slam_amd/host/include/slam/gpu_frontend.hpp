@@ -20,6 +20,8 @@ public:
     void configure(int maxFeatures, int pyramidLevels, int winSize, int orbLevels, int device = 0);
     /* histogram-equalise every frame before it is used (config/vins_mono.yaml:104 `equalize`) */
     void setEqualize(bool on);
+    /* VFE_EQ_NONE / VFE_EQ_HIST / VFE_EQ_CLAHE (`histogram_method`, docs/reference/15_openvins_smartphone_config.md:111) */
+    void setEqualizeMode(int mode);
     /* each returns false and records lastError() on failure; never throws */
     bool detectShiTomasi(const ImageView& img, int maxCorners, double quality, double minDistance, std::vector<float>& xy);
     bool orbExtract(const ImageView& img, int nFeatures, float scaleFactor, int nLevels, int fastThreshold,
@@ -35,7 +37,7 @@ private:
     bool fail(int rc);
     vfe_ctx* ctx_ = nullptr;
     vfe_config cfg_{0, 0, 0, 1000, 4, 21, 0};
-    bool equalize_ = false;
+    int equalize_ = 0;
     std::string error_;
 };
 

@@ -14,9 +14,11 @@ void GpuFrontEnd::configure(int maxFeatures, int pyramidLevels, int winSize, int
     cfg_.orb_levels = orbLevels;
 }
 
-void GpuFrontEnd::setEqualize(bool on) {
-    equalize_ = on;
-    if (ctx_) (void)vfe_set_equalize(ctx_, on ? 1 : 0);
+void GpuFrontEnd::setEqualize(bool on) { setEqualizeMode(on ? VFE_EQ_HIST : VFE_EQ_NONE); }
+
+void GpuFrontEnd::setEqualizeMode(int mode) {
+    equalize_ = (mode == VFE_EQ_HIST || mode == VFE_EQ_CLAHE) ? mode : VFE_EQ_NONE;
+    if (ctx_) (void)vfe_set_equalize(ctx_, equalize_);
 }
 
 void GpuFrontEnd::release() {
@@ -36,7 +38,7 @@ bool GpuFrontEnd::ensure(const ImageView& img) {
     cfg_.max_height = img.rows > cfg_.max_height ? img.rows : cfg_.max_height;
     const int rc = vfe_create(&cfg_, &ctx_);
     if (rc != VFE_OK) { ctx_ = nullptr; return fail(rc); }
-    (void)vfe_set_equalize(ctx_, equalize_ ? 1 : 0);
+    (void)vfe_set_equalize(ctx_, equalize_);
     error_.clear();
     return true;
 }
