@@ -173,6 +173,20 @@ int vfe_dev_klt_track_bidir(const vfe_dimg* prev_levels, const vfe_dimg* next_le
 int vfe_dev_corner_subpix(const vfe_dimg* img, float* pts, const int* n_pts, int pts_cap, int win, int zero_zone,
                           int max_iter, double eps, void* stream);
 
+/* Outlier rejection with the epipolar constraint, cv::findFundamentalMat(pts1, pts2, FM_RANSAC, threshold,
+ * confidence, mask)-shaped (`F_threshold: 1.0`, reference config/vins_mono.yaml:101): 7-point minimal solver,
+ * error = larger squared point-to-epipolar-line distance, adaptive iteration count (at most max_iters <= 1024).
+ * Deterministic for a given seed and independent of scheduling.
+ *  pts1/pts2 [batch][pts_cap][2] (pts_cap <= 2048); n_pts [batch] (device; NULL = pts_cap per frame);
+ *  status [batch][pts_cap] in/out: non-zero entries take part, on return 1 = inlier, 0 = rejected;
+ *  F_out [batch][9] row-major (zeros when fewer than 8 points take part -- nothing is rejected then -- or when
+ *  no model was found -- everything is rejected); inliers [batch].
+ *  workspace: vfe_fundamental_workspace(batch) bytes, 256-byte aligned. */
+size_t vfe_fundamental_workspace(int batch);
+int vfe_dev_fundamental_ransac(const float* pts1, const float* pts2, const int* n_pts, int pts_cap, int batch,
+                               uint8_t* status, double threshold, double confidence, int max_iters, unsigned seed,
+                               double* F_out, int* inliers, void* workspace, size_t workspace_bytes, void* stream);
+
 /* cv::undistortPoints (no R, no P): pixel positions -> normalised, undistorted coordinates for the
  * radial-tangential model the configs carry (`camera.k1, k2, p1, p2`, reference
  * config/vins_mono.yaml:32-35).  camera4 = {fx, fy, cx, cy}, dist5 = {k1, k2, p1, p2, k3} (host

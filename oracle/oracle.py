@@ -204,6 +204,20 @@ def corner_subpix(img, pts, win=5, zero_zone=-1, max_iter=30, eps=0.01):
     return p
 
 
+def fundamental_ransac(p1, p2, status=None, threshold=1.0, confidence=0.99, max_iters=1000, seed=0x5EED):
+    """-> (F [3,3] float64, status [n] uint8, inlier count)"""
+    a = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    st = np.ones(len(a), np.uint8) if status is None else np.array(status, np.uint8).copy()
+    F = np.zeros(9, np.float64)
+    L = lib()
+    L.ora_fundamental_ransac.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_int,
+                                         C.c_double, C.c_double, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+    cnt = L.ora_fundamental_ransac(_p(a, C.c_float), _p(b, C.c_float), _p(st, C.c_uint8), len(a), float(threshold),
+                                   float(confidence), int(max_iters), int(seed), _p(F, C.c_double))
+    return F.reshape(3, 3), st, cnt
+
+
 def fast9(img, threshold, nms=True):
     img, p = _u8(img)
     h, w = img.shape

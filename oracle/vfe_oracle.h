@@ -102,6 +102,11 @@ int ora_subpix_mask(int win, int zero_zone, float* mask);
 int ora_corner_subpix(const uint8_t* img, int w, int h, int step, float* pts, int n, int win, int zero_zone,
                       int max_iter, double eps);
 
+/* cv::findFundamentalMat(FM_RANSAC) as an outlier filter (`F_threshold`, config/vins_mono.yaml:101); see
+ * ora_geom.cpp for the sampling and solver conventions.  Returns the inlier count. */
+int ora_fundamental_ransac(const float* p1, const float* p2, uint8_t* status, int n, double threshold,
+                           double confidence, int max_iters, uint32_t seed, double* F_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,6 +269,39 @@ def test_corner_subpix_bit_exact(cuda, win, zero_zone, max_iter, eps):
     assert moved > 200
 
 
+def test_fundamental_ransac_bit_exact(cuda):
+    """Epipolar outlier rejection (`F_threshold: 1.0`, config/vins_mono.yaml:101): model, mask and inlier count equal
+    the CPU restatement bit for bit -- frames with few / many outliers, a partial status mask, ragged counts, fewer
+    than 8 points, coincident points (no model)."""
+    import torch
+    from two_view import two_view
+    cap = 1000
+    cases = [two_view(300, 0.2, 0.3, 1), two_view(1000, 0.4, 0.5, 2), two_view(50, 0.1, 0.2, 3), two_view(200, 0.0, 0.0, 4),
+             two_view(8, 0.0, 0.1, 5), two_view(7, 0.0, 0.1, 6), two_view(400, 0.6, 0.4, 7)]
+    B = len(cases) + 1
+    p1 = np.zeros((B, cap, 2), np.float32); p2 = np.zeros((B, cap, 2), np.float32)
+    st = np.zeros((B, cap), np.uint8); n = np.zeros(B, np.int32)
+    rng = np.random.default_rng(5)
+    for b, (x1, x2, _, _) in enumerate(cases):
+        n[b] = len(x1); p1[b, :n[b]] = x1; p2[b, :n[b]] = x2
+        st[b, :n[b]] = 1 if b != 0 else (rng.random(n[b]) < 0.8)
+    n[B - 1] = 40; p1[B - 1, :40] = [100.0, 50.0]; p2[B - 1, :40] = [101.0, 50.5]; st[B - 1, :40] = 1
+    d_st = torch.from_numpy(st).to(cuda)
+    F, inl = capi.fundamental_ransac(torch.from_numpy(p1).to(cuda), torch.from_numpy(p2).to(cuda), d_st,
+                                     torch.from_numpy(n).to(cuda), 1.0, 0.99, 1000, seed=1234)
+    F = F.cpu().numpy(); inl = inl.cpu().numpy(); got = d_st.cpu().numpy()
+    for b in range(B):
+        rF, rst, rc = ora.fundamental_ransac(p1[b, :n[b]], p2[b, :n[b]], st[b, :n[b]], 1.0, 0.99, 1000, seed=1234)
+        assert inl[b] == rc, f"frame {b}: inliers {inl[b]} vs {rc}"
+        assert np.array_equal(got[b, :n[b]], rst), f"frame {b}: mask"
+        assert np.array_equal(F[b].view(np.uint64), rF.view(np.uint64)), f"frame {b}: model"
+    assert inl[4] == 8 and inl[5] == 7 and not F[5].any()  # 7 points: nothing rejected, no model
+    assert inl[B - 1] == 0 and not got[B - 1].any()       # coincident points: no model, all rejected
+    truth = cases[1][2]
+    kept = got[1, :n[1]].astype(bool)
+    assert (kept & ~truth).sum() <= 0.05 * kept.sum() and (kept & truth).sum() >= 0.5 * truth.sum()
+
+
 def _oracle_step(prev, cur, pts, n, q, d, levels, w, h):
     nxt, st, _ = ora.klt_track(prev, cur, pts, 21, levels - 1)
     r = np.rint(nxt)

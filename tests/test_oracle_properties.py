@@ -244,6 +244,28 @@ def test_corner_subpix_finds_an_analytic_corner():
     assert np.array_equal(ora.corner_subpix(flat, [[20.5, 30.25]]), np.array([[20.5, 30.25]], np.float32))
 
 
+def test_fundamental_ransac_separates_outliers():
+    """Noisy two-view correspondences with 30 % gross outliers: the kept set is almost pure, most true inliers are
+    kept, the model has rank 2 and explains the clean correspondences; the same seed gives the same answer."""
+    from two_view import two_view
+    x1, x2, truth, _ = two_view(500, 0.3, 0.3, 11)
+    F, st, cnt = ora.fundamental_ransac(x1, x2, None, 1.0, 0.99, 1000, seed=7)
+    kept = st.astype(bool)
+    assert cnt == kept.sum() > 0.6 * truth.sum()
+    assert (kept & ~truth).sum() <= 0.03 * kept.sum()
+    assert abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-12
+    c1, c2, _, _ = two_view(500, 0.0, 0.0, 11)
+    h1 = np.column_stack([c1, np.ones(len(c1))]); h2 = np.column_stack([c2, np.ones(len(c2))])
+    l2 = h1 @ F.T
+    dist = np.abs((h2 * l2).sum(axis=1)) / np.hypot(l2[:, 0], l2[:, 1])
+    assert np.median(dist) < 1.0
+    F2, st2, cnt2 = ora.fundamental_ransac(x1, x2, None, 1.0, 0.99, 1000, seed=7)
+    assert cnt2 == cnt and np.array_equal(st2, st) and np.array_equal(F2, F)
+    # fewer than 8 points: nothing is rejected
+    F3, st3, cnt3 = ora.fundamental_ransac(x1[:5], x2[:5])
+    assert cnt3 == 5 and st3.all() and not F3.any()
+
+
 def test_undistort_points_inverts_the_radtan_model():
     """Distort normalised points with the plumb-bob model, project, undistort: the fixed-point iteration
     recovers them (tightly near the principal point, where five iterations suffice)."""

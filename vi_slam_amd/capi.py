@@ -68,6 +68,9 @@ SIGNATURES = {
                                           C.c_double, C.c_double, C.c_double, _P]),
     "vfe_dev_undistort_points": (C.c_int, [_P, _P, C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "vfe_dev_corner_subpix": (C.c_int, [_DI, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P]),
+    "vfe_fundamental_workspace": (C.c_size_t, [C.c_int]),
+    "vfe_dev_fundamental_ransac": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_double, C.c_double, C.c_int, C.c_uint, _P, _P,
+                                             _P, C.c_size_t, _P]),
     "vfe_dev_compact_tracks": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "vfe_dev_append_points": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "vfe_frontend_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -284,6 +287,21 @@ def corner_subpix(img, pts, n_pts=None, win=5, zero_zone=-1, max_iter=30, eps=0.
     check(lib().vfe_dev_corner_subpix(C.byref(dimg(img)), _ptr(pts), _ptr(n_pts) if n_pts is not None else None, cap, win,
                                       zero_zone, max_iter, float(eps), _stream()))
     return pts
+
+
+def fundamental_ransac(pts1, pts2, status, n_pts=None, threshold=1.0, confidence=0.99, max_iters=1000, seed=0x5EED):
+    """Epipolar outlier rejection; pts1/pts2 [B, cap, 2] float32 cuda, status [B, cap] uint8 cuda (in/out).
+    -> (F [B, 3, 3] float64, inliers [B] int32)"""
+    import torch
+    b, cap, _ = pts1.shape
+    F = torch.zeros((b, 3, 3), dtype=torch.float64, device=pts1.device)
+    inl = torch.zeros(b, dtype=torch.int32, device=pts1.device)
+    nbytes = lib().vfe_fundamental_workspace(b)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts1.device)
+    check(lib().vfe_dev_fundamental_ransac(_ptr(pts1), _ptr(pts2), _ptr(n_pts) if n_pts is not None else None, cap, b,
+                                           _ptr(status), float(threshold), float(confidence), int(max_iters), int(seed),
+                                           _ptr(F), _ptr(inl), _ptr(ws), nbytes, _stream()))
+    return F, inl
 
 
 def compact_tracks(pts, status, n_pts, width, height, border=1):
