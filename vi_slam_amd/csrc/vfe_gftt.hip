@@ -5,7 +5,7 @@
  *                smaller eigenvalue, all staged through LDS tiles with halos; fused with the
  *                frame maximum (atomic) and 3x3 non-max suppression, so the float map never
  *                goes to HBM.  Local maxima are appended to a per-frame candidate list as
- *                64-bit keys (score bits << 32 | linear index).  Candidates that cannot pass
+ *                64-bit keys (score bits << 32 | y << 16 | x: same order as the linear index).  Candidates that cannot pass
  *                the final quality threshold are dropped early against the running maximum
  *                (a lower bound of the final one), which only removes keys the exact filter
  *                would remove anyway.
@@ -25,11 +25,15 @@
 #define SEL_M 8192
 #define SEED_CELLS 8192 /* LDS grid of tracked points: heads + two node arrays alias the 64 KiB sort buffer */
 #define SEED_NODES 4096
+#define SEL_M_FIRST 2048 /* first batch of the ordered walk: usually enough, and sorts 5x faster than a full one */
+#define WALK_CELLS 24576 /* LDS min-distance grid of the corners accepted in this call */
+#define WALK_NODES 4096
 
 struct SelParams {
     int W, H, max_corners;
     double quality;
     int use_grid, cell, gw, gh;
+    u32 cell_magic; /* ceil(2^32 / cell): v / cell = umulhi(v, cell_magic) for v < 65536, cell > 1 */
     u32 md2i;
     const u32* frame_max;
     const u32* cand_count;
@@ -49,6 +53,9 @@ struct SelParams {
 
 __device__ static inline u32 ld_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ static inline void st_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+/* v / cell for 0 <= v < 65536 */
+__device__ static inline int cell_of(int v, int cell, u32 magic) { return cell > 1 ? (int)__umulhi((u32)v, magic) : v; }
 
 /* inclusive suffix scan of 1024 values held one per thread; returns sum over threads >= tid */
 __device__ static inline u32 block_suffix_scan(u32 v, u32 (*buf)[SEL_THREADS]) {
@@ -75,19 +82,33 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     __shared__ u32 s_cnt;
     __shared__ u32 s_dmin;
     __shared__ int s_nacc;
+    __shared__ unsigned short w_heads[WALK_CELLS]; /* 0 = empty, else node + 1 */
+    __shared__ u32 w_xy[WALK_NODES];               /* x | y << 16 */
+    __shared__ unsigned short w_next[WALK_NODES];
 
     const int b = blockIdx.x, tid = threadIdx.x;
     __shared__ u32 s_segn[GF_NSEG];
     if (tid < GF_NSEG) s_segn[tid] = min(p.cand_count[(b * GF_NSEG + tid) * GF_CSTRIDE], p.seg_cap);
     u64* keys = p.cand + (size_t)b * GF_NSEG * p.seg_cap;
-/* visit every candidate key of this frame */
-#define FOR_EACH_KEY(k)                                              \
-    for (int sg_ = 0; sg_ < GF_NSEG; sg_++) {                         \
-        const u32 cn_ = s_segn[sg_];                                 \
-        u64* kp_ = keys + (size_t)sg_ * p.seg_cap;                   \
-        for (u32 i_ = tid; i_ < cn_; i_ += SEL_THREADS) {            \
-            const u64 k = kp_[i_];
-#define END_EACH_KEY }}
+    __syncthreads();
+    /* Every pass below visits all candidate keys of the frame.  The first SEL_THREADS keys of each segment (all of
+     * them unless the frame is unusually busy) are loaded once, one per thread and segment, and live in registers;
+     * only the rest is re-read from memory.  f(key, slot) returns true to clear the key (0 = no key). */
+    u64 rk[GF_NSEG];
+#pragma unroll
+    for (int sg = 0; sg < GF_NSEG; sg++) rk[sg] = (u32)tid < s_segn[sg] ? keys[(size_t)sg * p.seg_cap + tid] : 0ull;
+    auto for_each_key = [&](auto&& f) {
+#pragma unroll
+        for (int sg = 0; sg < GF_NSEG; sg++) {
+            if (rk[sg] != 0ull && f(rk[sg])) rk[sg] = 0ull;
+            const u32 cn = s_segn[sg];
+            u64* kp = keys + (size_t)sg * p.seg_cap;
+            for (u32 i = tid + SEL_THREADS; i < cn; i += SEL_THREADS) {
+                const u64 k = kp[i];
+                if (k != 0ull && f(k)) kp[i] = 0ull;
+            }
+        }
+    };
     const float maxv = __uint_as_float(p.frame_max[b * GF_CSTRIDE]);
     const float thr = (float)((double)maxv * p.quality);
     const u64 lowkey = ((u64)__float_as_uint(thr) << 32) | 0xFFFFFFFFull; /* valid keys are > lowkey */
@@ -111,6 +132,13 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
      * global grid and are met during the walk. */
     const int cells = p.gw * p.gh;
     const bool lds_seeds = p.use_grid && ns > 0 && cells <= SEED_CELLS && ns <= SEED_NODES;
+    /* The corners accepted below go into a grid in LDS when it fits (the walk is a chain of dependent lookups,
+     * each a round trip to L2 otherwise); tracked points that were not filtered up front stay in the global grid
+     * and are checked there as well. */
+    const bool lds_walk = p.use_grid && cells <= WALK_CELLS && limit <= WALK_NODES;
+    const bool global_grid = p.use_grid && (!lds_walk || (ns > 0 && !lds_seeds));
+    if (lds_walk)
+        for (int c = tid; c < cells; c += SEL_THREADS) w_heads[c] = 0;
     u32* g_heads = reinterpret_cast<u32*>(s_keys);       /* [SEED_CELLS] 0 = empty, else node + 1 */
     u32* g_xy = g_heads + SEED_CELLS;                    /* [SEED_NODES] x | y << 16 */
     u32* g_next = g_xy + SEED_NODES;                     /* [SEED_NODES] */
@@ -123,7 +151,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
         for (int s = tid; s < ns; s += SEL_THREADS) {
             const int sx = __float2int_rn(sd[2 * s]), sy = __float2int_rn(sd[2 * s + 1]);
             if (sx < 0 || sy < 0 || sx >= p.W || sy >= p.H) continue;
-            const int c = (sy / p.cell) * p.gw + sx / p.cell;
+            const int c = cell_of(sy, p.cell, p.cell_magic) * p.gw + cell_of(sx, p.cell, p.cell_magic);
             if (lds_seeds) {
                 g_xy[s] = (u32)sx | ((u32)sy << 16);
                 g_next[s] = atomicExch(&g_heads[c], (u32)s + 1);
@@ -140,30 +168,39 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     /* how many candidates pass the exact threshold (and are not blocked by a tracked point) */
     u32 mine = 0;
     if (lds_seeds) {
-        FOR_EACH_KEY(k)
-            if (k > lowkey) {
-                const u32 idx = (u32)k;
-                const int y = (int)(idx / (u32)p.W), x = (int)(idx - (u32)y * (u32)p.W);
-                const int xc = x / p.cell, yc = y / p.cell;
-                const int x1 = max(0, xc - 1), x2 = min(p.gw - 1, xc + 1);
-                const int y1 = max(0, yc - 1), y2 = min(p.gh - 1, yc + 1);
-                bool blocked = false;
-                for (int yy = y1; yy <= y2 && !blocked; yy++)
-                    for (int xx = x1; xx <= x2 && !blocked; xx++) {
-                        u32 n = g_heads[yy * p.gw + xx];
-                        while (n) {
-                            const u32 q = g_xy[n - 1];
-                            const int dx = x - (int)(q & 0xFFFF), dy = y - (int)(q >> 16);
-                            if ((u32)(dx * dx + dy * dy) < p.md2i) { blocked = true; break; }
-                            n = g_next[n - 1];
-                        }
-                    }
-                if (blocked) kp_[i_] = 0ull; else mine++;
+        for_each_key([&](u64 k) {
+            if (!(k > lowkey)) return false;
+            const int y = (int)(((u32)k) >> 16), x = (int)(((u32)k) & 0xFFFFu);
+            const int xc = cell_of(x, p.cell, p.cell_magic), yc = cell_of(y, p.cell, p.cell_magic);
+            const int x1 = max(0, xc - 1), x2 = min(p.gw - 1, xc + 1);
+            const int y1 = max(0, yc - 1), y2 = min(p.gh - 1, yc + 1);
+            /* all nine cell heads first, then the (short) chains side by side */
+            u32 hd[9];
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                const int yy = yc - 1 + c / 3, xx = xc - 1 + c % 3;
+                hd[c] = (yy >= y1 && yy <= y2 && xx >= x1 && xx <= x2) ? g_heads[yy * p.gw + xx] : 0u;
             }
-        END_EACH_KEY
+            bool blocked = false, more = true;
+            while (more && !blocked) {
+                more = false;
+#pragma unroll
+                for (int c = 0; c < 9; c++)
+                    if (hd[c]) {
+                        const u32 q = g_xy[hd[c] - 1];
+                        const u32 nx = g_next[hd[c] - 1];
+                        const int dx = x - (int)(q & 0xFFFF), dy = y - (int)(q >> 16);
+                        if ((u32)(dx * dx + dy * dy) < p.md2i) blocked = true;
+                        hd[c] = nx;
+                        more = more || nx != 0;
+                    }
+            }
+            if (!blocked) mine++;
+            return blocked;
+        });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-        FOR_EACH_KEY(k) mine += (k > lowkey) ? 1u : 0u; END_EACH_KEY
+        for_each_key([&](u64 k) { mine += (k > lowkey) ? 1u : 0u; return false; });
     }
     const u32 total_valid = block_suffix_scan(mine, s_scan) /* value at tid 0 */;
     __shared__ u32 s_total;
@@ -174,14 +211,18 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     u64 U = ~0ull; /* exclusive upper bound of keys not yet consumed */
     u32 consumed = 0;
     int n_acc = 0;
+    u32 m_batch = SEL_M_FIRST;
     while (consumed < total && n_acc < limit) {
         u64 T;
-        if (total - consumed <= SEL_M) {
+        if (total - consumed <= m_batch) {
             T = lowkey + 1;
         } else {
-            /* MSD radix select: largest top range [T, U) holding <= SEL_M keys */
-            u64 prefix = 0;
-            int hi_shift = 64; /* keys are compared on bits [hi_shift, 64) against prefix */
+            /* MSD radix select: largest top range [T, U) holding <= m_batch keys */
+            /* keys are compared on bits [hi_shift, 64) against prefix; valid keys lie between the threshold and the
+             * frame maximum, so the bits those two share need no pass */
+            const u32 diff = __float_as_uint(thr) ^ __float_as_uint(maxv);
+            int hi_shift = diff ? 64 - __clz((int)diff) : 32;
+            u64 prefix = hi_shift == 64 ? 0ull : (((u64)__float_as_uint(maxv) << 32) >> hi_shift);
             T = 0;
             for (;;) {
                 const int bits = hi_shift >= 11 ? 11 : hi_shift;
@@ -189,10 +230,11 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                 const u32 nb = 1u << bits;
                 for (u32 i = tid; i <= 2048; i += SEL_THREADS) s_hist[i] = 0;
                 __syncthreads();
-                FOR_EACH_KEY(k)
+                for_each_key([&](u64 k) {
                     if (k > lowkey && k < U && (hi_shift == 64 || (k >> hi_shift) == prefix))
                         atomicAdd(&s_hist[(u32)(k >> shift) & (nb - 1)], 1u);
-                END_EACH_KEY
+                    return false;
+                });
                 __syncthreads();
                 const u32 h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
                 const u32 ss = block_suffix_scan(h0 + h1, s_scan);
@@ -204,9 +246,9 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const u32 d = 2 * tid + q;
-                    if (s_hist[d] <= SEL_M && (d == 0 || s_hist[d - 1] > SEL_M)) s_dmin = d;
+                    if (s_hist[d] <= m_batch && (d == 0 || s_hist[d - 1] > m_batch)) s_dmin = d;
                 }
-                if (tid == 0 && s_hist[2047] > SEL_M) s_dmin = 2048;
+                if (tid == 0 && s_hist[2047] > m_batch) s_dmin = 2048;
                 __syncthreads();
                 const u32 dmin = s_dmin;
                 const u32 taken = s_hist[dmin];
@@ -215,19 +257,20 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                     T = (hi_shift == 64 ? 0ull : (prefix << hi_shift)) | ((u64)dmin << shift);
                     break;
                 }
-                /* bin dmin-1 alone holds more than SEL_M keys: refine inside it */
+                /* bin dmin-1 alone holds more than m_batch keys: refine inside it */
                 prefix = (hi_shift == 64 ? 0ull : (prefix << bits)) | (u64)(dmin - 1);
                 hi_shift = shift;
             }
             if (T <= lowkey) T = lowkey + 1;
         }
         /* collect [T, U) */
-        FOR_EACH_KEY(k)
+        for_each_key([&](u64 k) {
             if (k >= T && k < U) {
                 const u32 pos = atomicAdd(&s_cnt, 1u);
                 if (pos < SEL_M) s_keys[pos] = k;
             }
-        END_EACH_KEY
+            return false;
+        });
         __syncthreads();
         const u32 taken = min(s_cnt, (u32)SEL_M);
         u32 n2 = 64;
@@ -257,15 +300,37 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                 const u32 i = base + lane;
                 const bool valid = i < taken;
                 const u64 key = valid ? s_keys[i] : 0ull;
-                const u32 idx = (u32)key;
-                const int y = (int)(idx / (u32)p.W), x = (int)(idx - (u32)y * (u32)p.W);
+                const int y = (int)(((u32)key) >> 16), x = (int)(((u32)key) & 0xFFFFu);
                 bool alive = valid;
                 int xc = 0, yc = 0;
                 if (p.use_grid) {
-                    xc = x / p.cell; yc = y / p.cell;
-                    if (alive) {
-                        const int x1 = max(0, xc - 1), x2 = min(p.gw - 1, xc + 1);
-                        const int y1 = max(0, yc - 1), y2 = min(p.gh - 1, yc + 1);
+                    xc = cell_of(x, p.cell, p.cell_magic); yc = cell_of(y, p.cell, p.cell_magic);
+                    const int x1 = max(0, xc - 1), x2 = min(p.gw - 1, xc + 1);
+                    const int y1 = max(0, yc - 1), y2 = min(p.gh - 1, yc + 1);
+                    if (alive && lds_walk) {
+                        /* all nine cell heads first, then the (short) chains side by side */
+                        u32 hd[9];
+#pragma unroll
+                        for (int c = 0; c < 9; c++) {
+                            const int yy = yc - 1 + c / 3, xx = xc - 1 + c % 3;
+                            hd[c] = (yy >= y1 && yy <= y2 && xx >= x1 && xx <= x2) ? w_heads[yy * p.gw + xx] : 0u;
+                        }
+                        bool more = true;
+                        while (more && alive) {
+                            more = false;
+#pragma unroll
+                            for (int c = 0; c < 9; c++)
+                                if (hd[c]) {
+                                    const u32 q = w_xy[hd[c] - 1];
+                                    const u32 nx = w_next[hd[c] - 1];
+                                    const int dx = x - (int)(q & 0xFFFF), dy = y - (int)(q >> 16);
+                                    if ((u32)(dx * dx + dy * dy) < p.md2i) alive = false;
+                                    hd[c] = nx;
+                                    more = more || nx != 0;
+                                }
+                        }
+                    }
+                    if (alive && global_grid) {
                         for (int yy = y1; yy <= y2 && alive; yy++)
                             for (int xx = x1; xx <= x2 && alive; xx++) {
                                 u32 n = ld_agent(&heads[yy * p.gw + xx]);
@@ -278,31 +343,60 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                             }
                     }
                 }
-                u64 mask = __ballot(alive);
-                while (mask && acc < limit) {
+                /* Serial part, registers only: take the alive candidates in rank order; each one taken kills the
+                 * lower-ranked ones within min_distance of it. */
+                u64 mask = __ballot(alive), taken_mask = 0;
+                int n_new = 0;
+                while (mask && acc + n_new < limit) {
                     const int l = __ffsll((long long)mask) - 1;
-                    const int ax = __shfl(x, l), ay = __shfl(y, l);
-                    if (lane == l) {
-                        float* c = p.corners + ((size_t)b * p.max_corners + acc) * 2;
-                        c[0] = (float)x; c[1] = (float)y;
-                        if (p.scores) p.scores[(size_t)b * p.max_corners + acc] = __uint_as_float((u32)(key >> 32));
-                        if (p.use_grid) {
-                            const u32 n = (u32)(p.seed_cap + acc);
+                    taken_mask |= 1ull << l;
+                    n_new++;
+                    if (p.use_grid) {
+                        const int ax = __builtin_amdgcn_readlane(x, l), ay = __builtin_amdgcn_readlane(y, l);
+                        const int dx = x - ax, dy = y - ay;
+                        if ((u32)(dx * dx + dy * dy) < p.md2i) alive = false; /* includes lane l itself */
+                    } else if (lane == l) {
+                        alive = false;
+                    }
+                    mask = __ballot(alive) & ~((2ull << l) - 1ull);
+                }
+                /* Parallel part: the taken candidates write their corner and enter the grid. */
+                const bool took = (taken_mask >> lane) & 1ull;
+                const int my = acc + __popcll(taken_mask & ((1ull << lane) - 1ull));
+                if (took) {
+                    float* c = p.corners + ((size_t)b * p.max_corners + my) * 2;
+                    c[0] = (float)x; c[1] = (float)y;
+                    if (p.scores) p.scores[(size_t)b * p.max_corners + my] = __uint_as_float((u32)(key >> 32));
+                }
+                if (lds_walk) {
+                    /* two taken candidates may share a cell: everyone writes the head, whoever reads its own node back
+                     * has won and links to the head it saw before; the others go again */
+                    bool pending = took;
+                    while (__ballot(pending)) {
+                        unsigned short old = 0;
+                        if (pending) old = w_heads[yc * p.gw + xc];
+                        if (pending) w_heads[yc * p.gw + xc] = (unsigned short)(my + 1);
+                        if (pending && w_heads[yc * p.gw + xc] == (unsigned short)(my + 1)) {
+                            w_xy[my] = (u32)x | ((u32)y << 16);
+                            w_next[my] = old;
+                            pending = false;
+                        }
+                    }
+                } else if (p.use_grid) {
+                    u64 ins = taken_mask;
+                    while (ins) { /* global grid: one at a time */
+                        const int l = __ffsll((long long)ins) - 1;
+                        ins &= ins - 1;
+                        if (lane == l) {
+                            const u32 n = (u32)(p.seed_cap + my);
                             u32* hd = &heads[yc * p.gw + xc];
                             st_agent(&node_xy[n], (u32)x | ((u32)y << 16));
                             st_agent(&node_next[n], ld_agent(hd));
                             st_agent(hd, n + 1);
                         }
                     }
-                    acc++;
-                    if (p.use_grid) {
-                        const int dx = x - ax, dy = y - ay;
-                        if ((u32)(dx * dx + dy * dy) < p.md2i) alive = false;
-                    } else if (lane == l) {
-                        alive = false;
-                    }
-                    mask = __ballot(alive) & ~((2ull << l) - 1ull);
                 }
+                acc += n_new;
                 /* this chunk's insertions must be in L2 before the next chunk looks them up */
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -312,6 +406,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
         n_acc = s_nacc;
         consumed += taken;
         U = T;
+        m_batch = SEL_M;
     }
     if (tid == 0) p.counts[b] = n_acc;
 }
@@ -389,6 +484,7 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     SelParams p;
     p.W = d.w; p.H = d.h; p.max_corners = max_corners; p.quality = quality;
     p.use_grid = L.use_grid; p.cell = L.cell; p.gw = L.gw; p.gh = L.gh;
+    p.cell_magic = L.cell > 1 ? (u32)((0x100000000ull + (u64)L.cell - 1) / (u64)L.cell) : 0u;
     p.md2i = (u32)ceil(min_distance * min_distance);
     p.frame_max = frame_max; p.cand_count = cand_count; p.cand = (u64*)(ws + L.cand_off); p.seg_cap = L.seg_cap;
     p.heads = (u32*)(ws + L.heads_off); p.node_xy = (u32*)(ws + L.nxy_off); p.node_next = (u32*)(ws + L.nnext_off);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         nbuf = 0;
                     }
-                    if (isc[k]) stage[nbuf + __popcll(bm & lt_mask)] = ((u64)__float_as_uint(v[k]) << 32) | (u32)(N * W + X0 + k);
+                    if (isc[k]) stage[nbuf + __popcll(bm & lt_mask)] = ((u64)__float_as_uint(v[k]) << 32) | ((u32)N << 16) | (u32)(X0 + k);
                     nbuf += cnt;
                 }
             }
