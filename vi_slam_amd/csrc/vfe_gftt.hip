@@ -278,18 +278,19 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
         for (u32 i = taken + tid; i < n2; i += SEL_THREADS) s_keys[i] = 0;
         __syncthreads();
         if (tid == 0) s_cnt = 0;
-        /* bitonic sort, descending */
+        /* bitonic sort, descending: one compare-exchange per thread and step (pair t = elements i and i + j, i = t with
+         * a zero inserted at bit log2 j).  The 64 pairs of a wave stay inside one 128-element block as long as j <= 64,
+         * and a wave's LDS accesses stay in order: only steps that cross blocks, and the last step of a stage, need
+         * the workgroup barrier. */
         for (u32 k = 2; k <= n2; k <<= 1)
             for (u32 j = k >> 1; j > 0; j >>= 1) {
-                for (u32 i = tid; i < n2; i += SEL_THREADS) {
-                    const u32 l = i ^ j;
-                    if (l > i) {
-                        const u64 a = s_keys[i], c = s_keys[l];
-                        const bool desc = (i & k) == 0;
-                        if (desc ? (a < c) : (a > c)) { s_keys[i] = c; s_keys[l] = a; }
-                    }
+                for (u32 t = tid; t < n2 / 2; t += SEL_THREADS) {
+                    const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const u64 a = s_keys[i], c = s_keys[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < c) : (a > c)) { s_keys[i] = c; s_keys[l] = a; }
                 }
-                __syncthreads();
+                if (j > 64 || j == 1) __syncthreads();
             }
 
         /* wave-parallel greedy walk over the sorted batch */
@@ -343,22 +344,21 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                             }
                     }
                 }
-                /* Serial part, registers only: take the alive candidates in rank order; each one taken kills the
+                /* Serial part, scalar masks only: take the alive candidates in rank order; each one taken kills the
                  * lower-ranked ones within min_distance of it. */
-                u64 mask = __ballot(alive), taken_mask = 0;
+                u64 alive_m = __ballot(alive), taken_mask = 0;
                 int n_new = 0;
-                while (mask && acc + n_new < limit) {
-                    const int l = __ffsll((long long)mask) - 1;
+                while (alive_m && acc + n_new < limit) {
+                    const int l = __ffsll((long long)alive_m) - 1; /* lanes below l are dead or taken */
                     taken_mask |= 1ull << l;
                     n_new++;
                     if (p.use_grid) {
                         const int ax = __builtin_amdgcn_readlane(x, l), ay = __builtin_amdgcn_readlane(y, l);
                         const int dx = x - ax, dy = y - ay;
-                        if ((u32)(dx * dx + dy * dy) < p.md2i) alive = false; /* includes lane l itself */
-                    } else if (lane == l) {
-                        alive = false;
+                        alive_m &= ~__ballot((u32)(dx * dx + dy * dy) < p.md2i); /* includes lane l itself */
+                    } else {
+                        alive_m &= ~(1ull << l);
                     }
-                    mask = __ballot(alive) & ~((2ull << l) - 1ull);
                 }
                 /* Parallel part: the taken candidates write their corner and enter the grid. */
                 const bool took = (taken_mask >> lane) & 1ull;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                 }
                 acc += n_new;
                 /* this chunk's insertions must be in L2 before the next chunk looks them up */
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (global_grid) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (lane == 0) s_nacc = acc;
         }
