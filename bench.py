@@ -84,11 +84,17 @@ def main():
     ap.add_argument("--loss", type=float, default=0.05,
                     help="fraction of each stream's tracks dropped after every step (models feature loss, so that "
                          "every frame has corners to refill; the synthetic scene alone loses almost none)")
+    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
+                    help="run the detector's eigenvalue pass beside pyramid + tracker on a helper stream: auto = the library's "
+                         "rule (small batches only, so that per-kernel timings of the default run are not blurred by sharing "
+                         "the chip), on / off = force")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--rehearse-one-device", action="store_true",
                     help="multi-rank rehearsal on a box with one GPU: every rank uses cuda:0 and the barrier / max-reduce "
                          "go over gloo (RCCL refuses two ranks on one device); not a measurement")
     args = ap.parse_args()
+    if args.overlap != "auto":
+        os.environ["VFE_OVERLAP"] = "1" if args.overlap == "on" else "0"  # read once by the library at its first step
 
     import torch
     import torch.distributed as dist
@@ -200,7 +206,7 @@ def main():
             "vs_baseline": None, "dtype": "u8/int32/f32", "data": "synthetic",
             "config": {"workload": "configs[1]: 1920x1080 streams, 1000 Shi-Tomasi corners + 4-level KLT (win 21) + refill, "
                                    f"{B} independent streams per GPU per step, {args.loss:.0%} of the tracks dropped per step", "streams_per_gpu": B,
-                       "track_loss_per_step": args.loss,
+                       "track_loss_per_step": args.loss, "overlap": args.overlap,
                        "frame_bytes": W * H, "algo_bytes_per_frame": BYTES_PYR + BYTES_KLT + BYTES_DETECT,
                        "parallelism": f"streams sharded over {world} GPU(s), no collective"},
             "frontend_frac_of_hbm_roofline": value / world * (BYTES_PYR + BYTES_KLT + BYTES_DETECT) / (HBM_PEAK_GBS * 1e9),

@@ -2,6 +2,8 @@
  * The batched form of what a framework adapter does in one processImage call
  * (reference call path: src/slam/slam_engine.cpp:94-119 -> adapters' feedImage). */
 #include "vfe_common.h"
+#include "vfe_gftt.h"
+#include <cstdlib>
 
 /* stable compaction of surviving tracks, one workgroup per stream */
 __global__ __launch_bounds__(256) void k_compact(const float* __restrict__ pts, const uint8_t* __restrict__ status,
@@ -92,6 +94,29 @@ extern "C" size_t vfe_frontend_workspace(int width, int height, int batch, int m
     return fe_layout(width, height, batch, max_corners).total;
 }
 
+/* helper stream + fork/join events, one set per host thread and device, created on first use */
+struct AuxStream { hipStream_t s; hipEvent_t fork, join; };
+static AuxStream* aux_stream() {
+    static thread_local AuxStream pool[32];
+    static thread_local bool made[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    if (!made[dev]) {
+        AuxStream a;
+        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        pool[dev] = a; made[dev] = true;
+    }
+    return &pool[dev];
+}
+/* side-by-side execution pays when the batch is too small to fill the chip; VFE_OVERLAP=0/1 forces it off/on */
+static bool fe_overlap(int batch, int w, int h) {
+    static const int forced = [] { const char* e = getenv("VFE_OVERLAP"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0;
+    return (long long)batch * w * h <= 8ll * 1920 * 1080;
+}
+
 extern "C" int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
                                      float* pts, int* n_pts, int* n_tracked, int max_corners,
                                      double quality, double min_distance,
@@ -113,12 +138,26 @@ extern "C" int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg
     uint8_t* status = (uint8_t*)(ws + L.status_off);
     float* corners = (float*)(ws + L.corners_off);
     int* counts = (int*)(ws + L.counts_off);
+    /* The detector's first half (eigenvalue map + candidates) depends on the new frame only, the tracker on both
+     * pyramids: with few frames in the batch neither fills the chip, so they run side by side -- the first half on a
+     * helper stream forked from the caller's stream here and joined before the selection. */
+    hipStream_t st = (hipStream_t)stream;
+    AuxStream* aux = fe_overlap(batch, w, h) ? aux_stream() : nullptr;
+    if (aux) {
+        VFE_HIP(hipEventRecord(aux->fork, st));
+        VFE_HIP(hipStreamWaitEvent(aux->s, aux->fork, 0));
+        if ((rc = gf_eig_phase(&next_levels[0], cap, quality, min_distance, cap, ws + L.gf_off, L.gf_bytes, aux->s))) return rc;
+        VFE_HIP(hipEventRecord(aux->join, aux->s));
+    }
     if ((rc = vfe_dev_build_pyramid(next_levels, nlevels, stream))) return rc;
     if ((rc = vfe_dev_klt_track(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
                                 win, max_iter, eps, min_eig_thr, 0, stream))) return rc;
     if ((rc = vfe_dev_compact_tracks(next_pts, status, n_pts, cap, batch, w, h, 1, pts, n_pts, stream))) return rc;
-    if (n_tracked) VFE_HIP(hipMemcpyAsync(n_tracked, n_pts, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    if ((rc = vfe_dev_good_features(&next_levels[0], cap, quality, min_distance, pts, n_pts, cap, corners, nullptr, counts,
-                                    ws + L.gf_off, L.gf_bytes, stream))) return rc;
+    if (n_tracked) VFE_HIP(hipMemcpyAsync(n_tracked, n_pts, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (aux) {
+        VFE_HIP(hipStreamWaitEvent(st, aux->join, 0));
+    } else if ((rc = gf_eig_phase(&next_levels[0], cap, quality, min_distance, cap, ws + L.gf_off, L.gf_bytes, st))) return rc;
+    if ((rc = gf_select_phase(&next_levels[0], cap, quality, min_distance, pts, n_pts, cap, corners, nullptr, counts,
+                              ws + L.gf_off, L.gf_bytes, st))) return rc;
     return vfe_dev_append_points(pts, n_pts, cap, batch, corners, counts, cap, stream);
 }

@@ -24,7 +24,15 @@ static inline EigGeom eig_geom(int w, int h, int batch) {
 }
 
 /* Enqueue the eigenvalue pass.  eigmap != NULL: write the float map only.  Otherwise: frame maxima
- * (as float bits, stride GF_CSTRIDE) and the candidate keys (score bits << 32 | y*W+x) of the 3x3
+ * (as float bits, stride GF_CSTRIDE) and the candidate keys (score bits << 32 | y << 16 | x) of the 3x3
  * local maxima, GF_NSEG lists of seg_cap keys per frame with their counters after the maxima. */
 void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_count, u64* cand, u32 seg_cap,
                      double quality, hipStream_t st);
+
+/* the two halves of vfe_dev_good_features: the first depends on the image only and may be enqueued on another
+ * stream, the second needs the tracked points; same workspace, same parameters */
+int gf_eig_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance, int seed_cap, void* workspace,
+                 size_t workspace_bytes, hipStream_t st);
+int gf_select_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance,
+                    const float* seeds_xy, const int* n_seeds, int seed_cap,
+                    float* corners_xy, float* scores, int* counts, void* workspace, size_t workspace_bytes, hipStream_t st);

@@ -448,10 +448,9 @@ extern "C" size_t vfe_good_features_workspace(int width, int height, int batch, 
     return gf_layout(width, height, batch, max_corners, seed_cap, 1.0).total;
 }
 
-extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, double quality, double min_distance,
-                                     const float* seeds_xy, const int* n_seeds, int seed_cap,
-                                     float* corners_xy, float* scores, int* counts,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+static int gf_check(const vfe_dimg* img, int max_corners, double quality, double min_distance, const float* seeds_xy,
+                    const int* n_seeds, int* seed_cap, const float* corners_xy, const int* counts, const void* workspace,
+                    size_t workspace_bytes, GfWs* L) {
     int rc = vfe_check_dimg(img, "img");
     if (rc) return rc;
     VFE_REQUIRE(img->width >= 8 && img->height >= 8, "image must be at least 8x8");
@@ -461,28 +460,52 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     VFE_REQUIRE(quality > 0 && quality < 1e6, "quality out of range");
     VFE_REQUIRE(min_distance >= 0 && min_distance < 32768, "min_distance out of range");
     VFE_REQUIRE(corners_xy && counts && workspace, "NULL output or workspace");
-    VFE_REQUIRE(seed_cap >= 0 && (seed_cap == 0 || !seeds_xy == !n_seeds), "seeds_xy and n_seeds go together");
+    VFE_REQUIRE(*seed_cap >= 0 && (*seed_cap == 0 || !seeds_xy == !n_seeds), "seeds_xy and n_seeds go together");
     VFE_REQUIRE(img->batch <= 65535, "batch too large");
-    if (!seeds_xy) seed_cap = 0;
-    const GfWs L = gf_layout(img->width, img->height, img->batch, max_corners, seed_cap, min_distance);
-    if (workspace_bytes < L.total) {
-        vfe_set_error("workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+    if (!seeds_xy) *seed_cap = 0;
+    *L = gf_layout(img->width, img->height, img->batch, max_corners, *seed_cap, min_distance);
+    if (workspace_bytes < L->total) {
+        vfe_set_error("workspace too small: need %zu bytes, got %zu", L->total, workspace_bytes);
         return VFE_E_NOMEM;
     }
     VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
+    return VFE_OK;
+}
+
+/* first half of the detector: everything that depends on the image only (clears the counters and grid heads,
+ * eigenvalue map + candidates).  May run on another stream than the second half. */
+int gf_eig_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance, int seed_cap, void* workspace,
+                 size_t workspace_bytes, hipStream_t st) {
+    GfWs L;
+    static const float dummy_c = 0.f; static const int dummy_n = 0;
+    int rc = gf_check(img, max_corners, quality, min_distance, seed_cap ? &dummy_c : nullptr, seed_cap ? &dummy_n : nullptr, &seed_cap,
+                      &dummy_c, &dummy_n, workspace, workspace_bytes, &L);
+    if (rc) return rc;
     char* ws = (char*)workspace;
     VFE_HIP(hipMemsetAsync(ws + L.hdr_off, 0, L.zero_bytes, st));
     u32* frame_max = (u32*)(ws + L.hdr_off);
     u32* cand_count = frame_max + (size_t)img->batch * GF_CSTRIDE;
-    DImg d = to_dimg(img);
     {
         ProfScope prof(VFE_K_GFTT_EIG, st);
-        gftt_eig_launch(d, nullptr, frame_max, cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality, st);
+        gftt_eig_launch(to_dimg(img), nullptr, frame_max, cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality, st);
     }
     VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
+/* second half: ordered selection against the tracked points */
+int gf_select_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance,
+                    const float* seeds_xy, const int* n_seeds, int seed_cap,
+                    float* corners_xy, float* scores, int* counts, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    GfWs L;
+    int rc = gf_check(img, max_corners, quality, min_distance, seeds_xy, n_seeds, &seed_cap, corners_xy, counts, workspace,
+                      workspace_bytes, &L);
+    if (rc) return rc;
+    char* ws = (char*)workspace;
+    u32* frame_max = (u32*)(ws + L.hdr_off);
+    u32* cand_count = frame_max + (size_t)img->batch * GF_CSTRIDE;
     SelParams p;
-    p.W = d.w; p.H = d.h; p.max_corners = max_corners; p.quality = quality;
+    p.W = img->width; p.H = img->height; p.max_corners = max_corners; p.quality = quality;
     p.use_grid = L.use_grid; p.cell = L.cell; p.gw = L.gw; p.gh = L.gh;
     p.cell_magic = L.cell > 1 ? (u32)((0x100000000ull + (u64)L.cell - 1) / (u64)L.cell) : 0u;
     p.md2i = (u32)ceil(min_distance * min_distance);
@@ -493,10 +516,23 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     p.corners = corners_xy; p.scores = scores; p.counts = counts;
     {
         ProfScope prof(VFE_K_GFTT_SELECT, st);
-        hipLaunchKernelGGL(k_gftt_select, dim3(d.batch), dim3(SEL_THREADS), 0, st, p);
+        hipLaunchKernelGGL(k_gftt_select, dim3(img->batch), dim3(SEL_THREADS), 0, st, p);
     }
     VFE_LAUNCH_CHECK();
     return VFE_OK;
+}
+
+extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, double quality, double min_distance,
+                                     const float* seeds_xy, const int* n_seeds, int seed_cap,
+                                     float* corners_xy, float* scores, int* counts,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    GfWs L;
+    int sc = seed_cap;
+    int rc = gf_check(img, max_corners, quality, min_distance, seeds_xy, n_seeds, &sc, corners_xy, counts, workspace, workspace_bytes, &L);
+    if (rc) return rc;
+    if ((rc = gf_eig_phase(img, max_corners, quality, min_distance, sc, workspace, workspace_bytes, (hipStream_t)stream))) return rc;
+    return gf_select_phase(img, max_corners, quality, min_distance, seeds_xy, n_seeds, sc, corners_xy, scores, counts, workspace,
+                           workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int vfe_dev_min_eigen_map(const vfe_dimg* img, float* eig, void* stream) {
