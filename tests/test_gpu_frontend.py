@@ -122,6 +122,42 @@ def test_good_features_bit_exact(cuda, w, h, n, q, d):
     assert cnt[2] == 0  # constant image: no corners (reference fixture tests/test_slam_engine.cpp:94)
 
 
+@pytest.mark.parametrize("w,h,n,q,d", [(1920, 1080, 5000, 0.001, 3), (1280, 720, 3000, 0.0005, 2), (752, 480, 4500, 0.001, 4),
+                                       (640, 480, 20000, 0.0001, 0)])
+def test_good_features_busy_frames(cuda, w, h, n, q, d):
+    """Noise and a low quality level: tens of thousands of candidates (more per segment than a workgroup caches),
+    several sorted batches, more corners than the in-LDS grid holds, grids too fine for LDS, no grid at all."""
+    imgs = [synth.noise(41, w, h), synth.scene(synth.BASE_SEED + 6, w, h, 0)]
+    gf = capi.GoodFeatures(len(imgs), h, w, n, device=cuda)
+    c, s, cnt = gf(to_dev(imgs, cuda), q, d)
+    c, s, cnt = c.cpu().numpy(), s.cpu().numpy(), cnt.cpu().numpy()
+    for i, im in enumerate(imgs):
+        rxy, rsc = ora.good_features(im, n, q, d)
+        assert cnt[i] == len(rxy), f"frame {i}: {cnt[i]} vs {len(rxy)}"
+        assert np.array_equal(c[i, :cnt[i]], rxy), f"frame {i}"
+        assert np.array_equal(s[i, :cnt[i]].view(np.uint32), rsc.view(np.uint32))
+    assert cnt[0] > 1000
+
+
+def test_good_features_with_many_seeds(cuda):
+    """Refill on top of 900 tracked points at 1080p (the steady state of the benchmark) and on top of more tracked
+    points than the in-LDS grid of tracked points holds."""
+    import torch
+    w, h = 1920, 1080
+    im0, im1 = synth.scene(synth.BASE_SEED + 7, w, h, 0), synth.scene(synth.BASE_SEED + 7, w, h, 1)
+    for n, d, nseed in [(1000, 20, 900), (6000, 4, 5000)]:
+        seeds, _ = ora.good_features(im0, nseed, 0.001, d)
+        rxy, _ = ora.good_features(im1, n - len(seeds), 0.01, d, seeds=seeds)
+        gf = capi.GoodFeatures(1, h, w, n, seed_cap=n, device=cuda)
+        sd = torch.zeros((1, n, 2), dtype=torch.float32, device=cuda)
+        sd[0, :len(seeds)] = torch.from_numpy(seeds).to(cuda)
+        ns = torch.tensor([len(seeds)], dtype=torch.int32, device=cuda)
+        c, _, cnt = gf(to_dev([im1], cuda), 0.01, d, sd, ns)
+        k = int(cnt[0])
+        assert k == len(rxy) and k > 0, f"n={n}: {k} vs {len(rxy)}"
+        assert np.array_equal(c[0, :k].cpu().numpy(), rxy)
+
+
 def test_good_features_with_seeds(cuda):
     import torch
     w, h, n, d = 752, 480, 150, 30

@@ -30,6 +30,35 @@ def test_fast9_bit_exact(cuda, w, h, thr):
     assert cnt[2] == 0
 
 
+@pytest.mark.parametrize("w,h,thr", [(248, 16, 12), (249, 21, 12), (247, 29, 5), (496, 35, 30), (497, 62, 1), (16, 16, 3),
+                                     (1000, 14, 254), (15, 40, 8)])
+def test_fast9_strip_and_band_edges(cuda, w, h, thr):
+    """Widths either side of the 248-column strips, heights either side of the band heights, the smallest size of the
+    streaming kernel and sizes below it (tiled kernel), extreme thresholds; noise keeps every segment busy."""
+    imgs = [synth.noise(23, w, h), synth.scene(synth.BASE_SEED + 5, w, h, 0), (synth.noise(29, w, h) // 64 * 64).astype(np.uint8)]
+    kps, cnt = capi.fast9(to_dev(imgs, cuda), thr)
+    kps, cnt = kps.cpu().numpy(), cnt.cpu().numpy()
+    for i, im in enumerate(imgs):
+        ref = ora.fast9(im, thr)
+        assert cnt[i] == len(ref), f"frame {i}: {cnt[i]} vs {len(ref)}"
+        assert np.array_equal(kps[i, :cnt[i]], ref), f"frame {i}"
+
+
+def test_fast9_unaligned_rows(cuda):
+    """Rows that start at odd addresses take the byte-load path of the streaming kernel."""
+    import torch
+    w, h = 333, 97
+    im = synth.noise(31, w, h)
+    buf = torch.zeros((2, h, w + 7), dtype=torch.uint8, device=cuda)
+    view = buf[:, :, 3:3 + w]
+    view.copy_(torch.from_numpy(np.stack([im, im[::-1].copy()])).to(cuda))
+    kps, cnt = capi.fast9(view, 15)
+    kps, cnt = kps.cpu().numpy(), cnt.cpu().numpy()
+    for i, ref_im in enumerate([im, im[::-1].copy()]):
+        ref = ora.fast9(ref_im, 15)
+        assert cnt[i] == len(ref) and np.array_equal(kps[i, :cnt[i]], ref)
+
+
 def test_bgr2gray_bit_exact(cuda):
     import torch
     w, h = 641, 479

@@ -41,7 +41,6 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ static inline s16x2 as_s2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
 __device__ static inline unsigned as_u(s16x2 v) { return __builtin_bit_cast(unsigned, v); }
-__device__ static inline unsigned ldu32(const uint8_t* p) { unsigned v; __builtin_memcpy(&v, p, 4); return v; }
 /* (byte k of a) | (byte k of b) << 16 */
 __device__ static inline unsigned pair_bytes(int k, unsigned a, unsigned b) {
     return __builtin_amdgcn_perm(b, a, 0x0c040c00u + (unsigned)k * 0x00010001u);
