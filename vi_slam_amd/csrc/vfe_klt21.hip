@@ -342,6 +342,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             D = 1.f / D;
             float pdx = 0.f, pdy = 0.f;
             bool err_pass = false;
+            bool fresh = true; /* vJ holds a patch that is not in the LDS area yet */
             for (int j = 0;;) {
                 if (!inr) {
                     if (level == 0) status = 0;
@@ -349,7 +350,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 }
                 bilinear_weights(qx - (float)inx, qy - (float)iny, iw00, iw01, iw10, iw11);
                 const unsigned W0 = (unsigned)iw00 | ((unsigned)iw10 << 16), W1 = (unsigned)iw01 | ((unsigned)iw11 << 16);
-                store_patch<22>(vJ, P, area);
+                /* small steps keep the integer origin: the patch in the area is still the right one, only the
+                 * interpolation weights change */
+                if (fresh) store_patch<22>(vJ, P, area);
                 if (err_pass) {
                     /* residual: the template intensities are the same interpolation of the previous
                      * image at the window origin */
@@ -387,9 +390,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     err_pass = true;
                     qx = outx - half; qy = outy - half;
                 } else { qx = nx; qy = ny; }
-                inx = (int)floorf(qx); iny = (int)floorf(qy);
+                const int ninx = (int)floorf(qx), niny = (int)floorf(qy);
+                fresh = ninx != inx || niny != iny;
+                inx = ninx; iny = niny;
                 inr = !(inx < -win || inx >= J.w || iny < -win || iny >= J.h);
-                if (inr) fetch_patch<22>(J, jp, inx, iny, P, vJ);
+                if (inr && fresh) fetch_patch<22>(J, jp, inx, iny, P, vJ);
             }
         }
         if (sub == 0) {
