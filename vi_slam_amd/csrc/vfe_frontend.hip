@@ -3,6 +3,7 @@
  * (reference call path: src/slam/slam_engine.cpp:94-119 -> adapters' feedImage). */
 #include "vfe_common.h"
 #include "vfe_gftt.h"
+#include "vfe_klt.h"
 #include <cstdlib>
 
 /* stable compaction of surviving tracks, one workgroup per stream */
@@ -76,7 +77,7 @@ extern "C" int vfe_dev_append_points(float* pts, int* n_pts, int cap, int batch,
     return VFE_OK;
 }
 
-struct FeWs { size_t gf_off, gf_bytes, next_off, status_off, corners_off, counts_off, total; };
+struct FeWs { size_t gf_off, gf_bytes, next_off, status_off, corners_off, counts_off, order_off, total; };
 
 static FeWs fe_layout(int w, int h, int batch, int cap) {
     FeWs L; size_t o = 0;
@@ -85,6 +86,7 @@ static FeWs fe_layout(int w, int h, int batch, int cap) {
     L.status_off = o; o += align_up((size_t)batch * cap, 256);
     L.corners_off = o; o += align_up((size_t)batch * cap * 2 * sizeof(float), 256);
     L.counts_off = o; o += align_up((size_t)batch * sizeof(int), 256);
+    L.order_off = o; o += align_up((size_t)batch * cap * sizeof(unsigned short), 256); /* tracker's processing order */
     L.total = o;
     return L;
 }
@@ -150,8 +152,13 @@ extern "C" int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg
         VFE_HIP(hipEventRecord(aux->join, aux->s));
     }
     if ((rc = vfe_dev_build_pyramid(next_levels, nlevels, stream))) return rc;
-    if ((rc = vfe_dev_klt_track(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
-                                win, max_iter, eps, min_eig_thr, 0, stream))) return rc;
+    /* the tracker takes each frame's points tile by tile (neighbours share cache lines and tend to converge together);
+     * every point's result lands at its own index, so nothing downstream sees the order */
+    /* (not worth an extra launch when a handful of frames leaves most of the chip idle anyway) */
+    unsigned short* order = (cap <= 65536 && (long long)batch * cap >= 16384) ? (unsigned short*)(ws + L.order_off) : nullptr;
+    if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, order, st))) return rc;
+    if ((rc = klt_track_ordered(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
+                                win, max_iter, eps, min_eig_thr, 0, order, st))) return rc;
     if ((rc = vfe_dev_compact_tracks(next_pts, status, n_pts, cap, batch, w, h, 1, pts, n_pts, stream))) return rc;
     if (n_tracked) VFE_HIP(hipMemcpyAsync(n_tracked, n_pts, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (aux) {

@@ -18,6 +18,10 @@ struct KltParams {
     double min_eig_thr;
     int use_initial;
     unsigned total_work;
+    /* optional processing order [batch][cap]: the wave that would take points 4k .. 4k+3 of a frame takes points
+     * order[4k .. 4k+3] instead (a permutation of 0 .. n-1; entries past a frame's count are not read).  Results do
+     * not depend on it; neighbours in the image share cache lines and tend to need the same number of iterations. */
+    const unsigned short* order;
 };
 
 __device__ static inline int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
@@ -32,3 +36,12 @@ __device__ static inline void bilinear_weights(float a, float b, int& w00, int& 
 
 /* enqueue the 21x21 kernel for p.total_work (frame, point) items */
 void klt21_launch(const KltParams& p, hipStream_t stream);
+
+/* vfe_dev_klt_track with an optional processing order (see KltParams::order) */
+int klt_track_ordered(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                      const float* prev_pts, const int* n_pts, int pts_cap, float* next_pts, uint8_t* status, float* err,
+                      int win, int max_iter, double eps, double min_eig_thr, int use_initial_flow,
+                      const unsigned short* order, hipStream_t stream);
+/* fills order[batch][cap] with every frame's points sorted by image tile (counting sort, one workgroup per frame);
+ * cap <= 65536 */
+int klt_order_launch(const float* pts, const int* n_pts, int cap, int batch, int w, int h, unsigned short* order, hipStream_t stream);

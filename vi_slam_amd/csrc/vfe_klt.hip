@@ -178,11 +178,75 @@ __global__ __launch_bounds__(64) void k_klt(KltParams p) {
     }
 }
 
+#define ORD_CELLS 4096
+__global__ __launch_bounds__(256) void k_klt_order(const float* __restrict__ pts, const int* __restrict__ n_pts, int cap, int w, int h,
+                                                   int shift, int gx, int cells, unsigned short* __restrict__ order) {
+    __shared__ unsigned s_cnt[ORD_CELLS];
+    __shared__ unsigned s_scan[2][256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = n_pts ? max(0, min(n_pts[b], cap)) : cap;
+    const float* p = pts + (size_t)b * cap * 2;
+    unsigned short* o = order + (size_t)b * cap;
+    for (int c = tid; c < cells; c += 256) s_cnt[c] = 0;
+    __syncthreads();
+    auto cell_of_point = [&](int i) {
+        const int x = min(max((int)p[2 * i], 0), w - 1), y = min(max((int)p[2 * i + 1], 0), h - 1);
+        return (y >> shift) * gx + (x >> shift);
+    };
+    for (int i = tid; i < n; i += 256) atomicAdd(&s_cnt[cell_of_point(i)], 1u);
+    __syncthreads();
+    /* exclusive prefix over the tiles: thread t owns tiles 16t .. 16t+15 */
+    unsigned loc[ORD_CELLS / 256], sum = 0;
+#pragma unroll
+    for (int k = 0; k < ORD_CELLS / 256; k++) {
+        const int c = tid * (ORD_CELLS / 256) + k;
+        loc[k] = c < cells ? s_cnt[c] : 0u;
+        sum += loc[k];
+    }
+    int cur = 0;
+    s_scan[0][tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned v = s_scan[cur][tid];
+        if (tid >= off) v += s_scan[cur][tid - off];
+        s_scan[cur ^ 1][tid] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    unsigned run = s_scan[cur][tid] - sum;
+#pragma unroll
+    for (int k = 0; k < ORD_CELLS / 256; k++) {
+        const int c = tid * (ORD_CELLS / 256) + k;
+        if (c < cells) s_cnt[c] = run;
+        run += loc[k];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) o[atomicAdd(&s_cnt[cell_of_point(i)], 1u)] = (unsigned short)i;
+}
+
+int klt_order_launch(const float* pts, const int* n_pts, int cap, int batch, int w, int h, unsigned short* order, hipStream_t stream) {
+    VFE_REQUIRE(pts && order && cap > 0 && cap <= 65536 && batch > 0 && w > 0 && h > 0, "bad arguments for the point order");
+    int shift = 6; /* 64-pixel tiles, coarser for very large frames */
+    while ((long long)((w >> shift) + 1) * ((h >> shift) + 1) > ORD_CELLS) shift++;
+    const int gx = (w >> shift) + 1, cells = gx * ((h >> shift) + 1);
+    hipLaunchKernelGGL(k_klt_order, dim3(batch), dim3(256), 0, stream, pts, n_pts, cap, w, h, shift, gx, cells, order);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
 extern "C" int vfe_dev_klt_track(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
                                  const float* prev_pts, const int* n_pts, int pts_cap,
                                  float* next_pts, uint8_t* status, float* err,
                                  int win, int max_iter, double eps, double min_eig_thr, int use_initial_flow,
                                  void* stream) {
+    return klt_track_ordered(prev_levels, next_levels, nlevels, prev_pts, n_pts, pts_cap, next_pts, status, err, win, max_iter, eps,
+                             min_eig_thr, use_initial_flow, nullptr, (hipStream_t)stream);
+}
+
+int klt_track_ordered(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                      const float* prev_pts, const int* n_pts, int pts_cap, float* next_pts, uint8_t* status, float* err,
+                      int win, int max_iter, double eps, double min_eig_thr, int use_initial_flow,
+                      const unsigned short* order, hipStream_t stream) {
     VFE_REQUIRE(prev_levels && next_levels && nlevels >= 1 && nlevels <= KLT_MAX_LEVELS, "nlevels must be 1..8");
     VFE_REQUIRE(prev_pts && next_pts && status, "NULL point buffers");
     VFE_REQUIRE(pts_cap > 0, "pts_cap must be > 0");
@@ -208,6 +272,7 @@ extern "C" int vfe_dev_klt_track(const vfe_dimg* prev_levels, const vfe_dimg* ne
     p.next_pts = next_pts; p.status = status; p.err = err;
     p.win = win; p.max_iter = max_iter; p.epsilon = eps * eps; p.min_eig_thr = min_eig_thr;
     p.use_initial = use_initial_flow ? 1 : 0;
+    p.order = win == 21 ? order : nullptr; /* the generic kernel keeps the given order */
     const int PW = win + 3, DW = win + 1;
     const size_t smem = ((PW * PW + 15) & ~15) + (size_t)DW * DW * 4 + (size_t)((win * win + 1) & ~1) * 2 + (size_t)win * win * 4;
     ProfScope prof(VFE_K_KLT, (hipStream_t)stream);

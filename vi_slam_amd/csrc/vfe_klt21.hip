@@ -260,13 +260,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
         const unsigned idx = item * 4u + (unsigned)q;
         if (idx >= p.total_work) continue;
-        const int b = (int)(idx / (unsigned)p.cap), pt = (int)(idx - (unsigned)b * (unsigned)p.cap);
-        const size_t o = idx;
+        const int b = (int)(idx / (unsigned)p.cap), slot = (int)(idx - (unsigned)b * (unsigned)p.cap);
         const int n = p.n_pts ? min(p.n_pts[b], p.cap) : p.cap;
-        if (pt >= n) {
-            if (sub == 0) { p.status[o] = 0; if (p.err) p.err[o] = 0.f; }
+        if (slot >= n) {
+            if (sub == 0) { p.status[idx] = 0; if (p.err) p.err[idx] = 0.f; }
             continue;
         }
+        const int pt = p.order ? (int)p.order[idx] : slot;
+        const size_t o = (size_t)b * p.cap + pt;
         const float ppx = p.prev_pts[2 * o], ppy = p.prev_pts[2 * o + 1];
         float outx = p.use_initial ? p.next_pts[2 * o] : 0.f, outy = p.use_initial ? p.next_pts[2 * o + 1] : 0.f;
         int status = 1;
