@@ -379,3 +379,38 @@ def test_frontend_step_sequence(cuda, w, h, n, d, levels):
             assert n_tr[b] == ntr and n_pts[b] == len(ref[b]), f"t={t} b={b}: {n_tr[b]}/{n_pts[b]} vs {ntr}/{len(ref[b])}"
             assert np.array_equal(pts[b, :n_pts[b]].view(np.uint32), ref[b].view(np.uint32)), f"t={t} b={b}"
             assert ntr > 0.8 * n
+
+
+def test_frontend_step_many_streams_tile_order(cuda):
+    """Enough points in the batch (streams x capacity >= 16384) for the tracker to take each frame's points tile by tile:
+    48 streams that repeat three sequences, capacity 350; every stream equals the oracle's sequence and its repeats."""
+    import torch
+    w, h, n, d, levels, q = 480, 360, 350, 8, 3, 0.01
+    seeds = [synth.BASE_SEED + 12, synth.BASE_SEED + 13, synth.BASE_SEED + 14]
+    seq = [[synth.scene(s, w, h, t) for t in range(3)] for s in seeds]
+    B = 48
+    assert B * n >= 16384
+    fe = capi.FrontendStep(B, h, w, n, levels, 21, quality=q, min_distance=d, device=cuda)
+    frames = [to_dev([seq[b % 3][t] for b in range(B)], cuda) for t in range(3)]
+    pyr = [capi.alloc_pyramid(frames[0], levels), capi.alloc_pyramid(frames[0], levels)]
+    capi.build_pyramid(pyr[0])
+    ref = []
+    for k in range(3):
+        xy, _ = ora.good_features(seq[k][0], n, q, d)
+        ref.append(xy)
+    for b in range(B):
+        fe.pts[b, :len(ref[b % 3])] = torch.from_numpy(ref[b % 3]).to(cuda)
+        fe.n_pts[b] = len(ref[b % 3])
+    cur = 0
+    for t in range(1, 3):
+        nxt = cur ^ 1
+        pyr[nxt][0] = frames[t]
+        pts, n_pts, n_tr = fe.step(pyr[cur], pyr[nxt])
+        cur = nxt
+        pts, n_pts, n_tr = pts.cpu().numpy(), n_pts.cpu().numpy(), n_tr.cpu().numpy()
+        for k in range(3):
+            ref[k], ntr = _oracle_step(seq[k][t - 1], seq[k][t], ref[k], n, q, d, levels, w, h)
+        for b in range(B):
+            r = ref[b % 3]
+            assert n_pts[b] == len(r), f"t={t} b={b}: {n_pts[b]} vs {len(r)}"
+            assert np.array_equal(pts[b, :n_pts[b]].view(np.uint32), r.view(np.uint32)), f"t={t} b={b}"
