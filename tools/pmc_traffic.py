@@ -31,6 +31,24 @@ def main():
         wr = 1024.0 * (sum(write[k]) / len(write[k])) if write.get(k) else None
         out["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "launches": len(fetch.get(k, [])),
                              "total_bytes": (rd or 0.0) + (wr or 0.0)}
+    # bench.py names kernels by the library's profiling slots
+    for kernel, slot in (("k_klt21", "k_klt"), ("k_pyr_down_stream", "k_pyr_down")):
+        if kernel in out["kernels"]:
+            out["kernels"][slot] = out["kernels"][kernel]
+    # what limits the two big kernels: VALU issue = SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel duration x clock)
+    try:
+        valu = per_kernel(os.path.join(root, "pmc_valu"), "SQ_INSTS_VALU")
+        dur = {}
+        for row in csv.DictReader(open(os.path.join(root, "trace", "p_kernel_stats.csv"))):
+            dur[row["Name"].split("(")[0].replace("void ", "").split("<")[0]] = float(row["AverageNs"])
+        out["limiter"] = {}
+        for kernel, slot in (("k_klt21", "k_klt"), ("k_gftt_eig", "k_gftt_eig")):
+            if valu.get(kernel) and kernel in dur:
+                frac = (sum(valu[kernel]) / len(valu[kernel])) * 4.0 / (1024 * dur[kernel] * 2.4)
+                out["limiter"][slot] = ("VALU issue: SQ_INSTS_VALU x 4 cycles = %.0f%% of SIMD cycles (1024 SIMDs, 2.4 GHz; "
+                                        "profiles/%s_bench_pmc_valu.txt)" % (100 * frac, tag))
+    except Exception:
+        pass
     try:
         cfg = json.loads(open(os.path.join(root, "pmc_fetch.stdout")).read().strip().splitlines()[-1])
         out["streams_per_gpu"] = cfg["config"]["streams_per_gpu"]
