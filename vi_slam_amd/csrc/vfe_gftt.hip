@@ -371,12 +371,15 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                 if (lds_walk) {
                     /* two taken candidates may share a cell: everyone writes the head, whoever reads its own node back
                      * has won and links to the head it saw before; the others go again */
+                    /* (volatile: the read-back must come from LDS, where another lane's write may have landed on top
+                     * of this lane's; the compiler would otherwise forward the value just stored) */
+                    volatile unsigned short* vh = &w_heads[yc * p.gw + xc];
                     bool pending = took;
                     while (__ballot(pending)) {
                         unsigned short old = 0;
-                        if (pending) old = w_heads[yc * p.gw + xc];
-                        if (pending) w_heads[yc * p.gw + xc] = (unsigned short)(my + 1);
-                        if (pending && w_heads[yc * p.gw + xc] == (unsigned short)(my + 1)) {
+                        if (pending) old = *vh;
+                        if (pending) *vh = (unsigned short)(my + 1);
+                        if (pending && *vh == (unsigned short)(my + 1)) {
                             w_xy[my] = (u32)x | ((u32)y << 16);
                             w_next[my] = old;
                             pending = false;
