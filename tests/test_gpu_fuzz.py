@@ -107,3 +107,98 @@ def test_fuzz_orb(cuda, case):
         for f in ("x", "y", "size", "response", "angle"):
             assert np.array_equal(gk[f].view(np.uint32), rk[f].view(np.uint32)), f"{tag}: {f}"
         assert np.array_equal(gd, rd), f"{tag}: descriptors"
+
+
+def _oracle_step(prev, cur, pts, n, q, d, levels, w, h):
+    nxt, st, _ = ora.klt_track(prev, cur, pts, 21, levels - 1)
+    r = np.rint(nxt)
+    keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < w - 1) & (r[:, 1] >= 1) & (r[:, 1] < h - 1)
+    tracked = nxt[keep]
+    if n - len(tracked) > 0:
+        new, _ = ora.good_features(cur, n - len(tracked), q, d, seeds=tracked)
+        return (np.concatenate([tracked, new]) if len(new) else tracked), len(tracked)
+    return tracked, len(tracked)
+
+
+@pytest.mark.parametrize("case", range(6 * SCALE))
+def test_fuzz_frontend_steps(cuda, case):
+    """Two steady-state steps (pyramid, tracker, compaction, refill against the tracked points) on random shapes."""
+    import torch
+    rng = np.random.default_rng(4000 + case)
+    w, h = int(rng.integers(96, 520)), int(rng.integers(96, 320))
+    n = int(rng.integers(5, 400)); d = float(rng.choice([3, 5, 8, 12, 20, 33])); q = float(rng.choice([0.005, 0.01, 0.05]))
+    levels = capi.lk_max_level(w, h, 21, int(rng.integers(0, 4))) + 1
+    B = int(rng.integers(1, 4))
+    seeds = [int(rng.integers(1, 1 << 30)) for _ in range(B)]
+    seq = [[synth.scene(s, w, h, t) for t in range(3)] for s in seeds]
+    fe = capi.FrontendStep(B, h, w, n, levels, 21, quality=q, min_distance=d, device=cuda)
+    frames = [_dev([seq[b][t] for b in range(B)], cuda) for t in range(3)]
+    pyr = [capi.alloc_pyramid(frames[0], levels), capi.alloc_pyramid(frames[0], levels)]
+    capi.build_pyramid(pyr[0])
+    ref = []
+    for b in range(B):
+        k0 = int(rng.integers(0, n + 1))   # start with fewer points than the capacity, down to none
+        xy, _ = ora.good_features(seq[b][0], max(k0, 1), q, d)
+        xy = xy[:k0]
+        ref.append(xy)
+        fe.pts[b, :len(xy)] = torch.from_numpy(xy).to(cuda)
+        fe.n_pts[b] = len(xy)
+    cur = 0
+    for t in range(1, 3):
+        nxt = cur ^ 1
+        pyr[nxt][0] = frames[t]
+        pts, n_pts, n_tr = fe.step(pyr[cur], pyr[nxt])
+        cur = nxt
+        pts, n_pts, n_tr = pts.cpu().numpy(), n_pts.cpu().numpy(), n_tr.cpu().numpy()
+        for b in range(B):
+            ref[b], ntr = _oracle_step(seq[b][t - 1], seq[b][t], ref[b], n, q, d, levels, w, h)
+            tag = f"{w}x{h} n {n} d {d} q {q} L{levels} t={t} b={b}"
+            assert n_tr[b] == ntr and n_pts[b] == len(ref[b]), f"{tag}: {n_tr[b]}/{n_pts[b]} vs {ntr}/{len(ref[b])}"
+            assert np.array_equal(pts[b, :n_pts[b]].view(np.uint32), ref[b].view(np.uint32)), tag
+
+
+@pytest.mark.parametrize("case", range(6 * SCALE))
+def test_fuzz_match(cuda, case):
+    import torch
+    rng = np.random.default_rng(5000 + case)
+    nq, nt = int(rng.integers(1, 700)), int(rng.integers(0, 9000))
+    q = synth.descriptors(int(rng.integers(1, 1 << 20)), nq)
+    t = synth.descriptors(int(rng.integers(1, 1 << 20)), nt) if nt else np.zeros((0, 32), np.uint8)
+    for i in range(min(nq, nt, 40)):     # near-duplicates and exact ties
+        t[int(rng.integers(0, nt))] = synth.flip_bits(100 + i, q[i], int(rng.integers(0, 30)))
+    if nt > 10:
+        t[int(rng.integers(0, nt))] = t[int(rng.integers(0, nt))]
+    base = int(rng.integers(0, 1 << 20))
+    dq = torch.from_numpy(q).to(cuda)
+    dt = torch.from_numpy(t).to(cuda) if nt else torch.zeros((0, 32), dtype=torch.uint8, device=cuda)
+    idx, dist = capi.match_knn2(dq, dt, base_index=base)
+    ridx, rdist = ora.match_knn2(q, t, base)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dist.cpu().numpy(), rdist), f"nq {nq} nt {nt}"
+    ratio = float(rng.choice([0.6, 0.7, 0.8]))
+    assert np.array_equal(capi.ratio_test(idx, dist, ratio).cpu().numpy(), ora.ratio_test(ridx, rdist, ratio))
+
+
+@pytest.mark.parametrize("case", range(6 * SCALE))
+def test_fuzz_preprocess_and_refine(cuda, case):
+    """equalizeHist, CLAHE and cornerSubPix on random shapes, grids and windows."""
+    import torch
+    rng = np.random.default_rng(6000 + case)
+    w, h = int(rng.integers(40, 520)), int(rng.integers(40, 300))
+    imgs = _images(rng, w, h, 2)
+    t = _dev(imgs, cuda)
+    eq = capi.equalize_hist(t).cpu().numpy()
+    tx, ty = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    clip = float(rng.choice([0.0, 1.5, 4.0, 10.0, 40.0]))
+    cl = capi.clahe(t, clip, tx, ty).cpu().numpy()
+    for i, im in enumerate(imgs):
+        assert np.array_equal(eq[i], ora.equalize_hist(im)), f"equalize {w}x{h} frame {i}"
+        assert np.array_equal(cl[i], ora.clahe(im, clip, tx, ty)), f"clahe {w}x{h} clip {clip} grid {tx}x{ty} frame {i}"
+    win = int(rng.integers(1, 11)); zz = int(rng.choice([-1, -1, 0, 1])); it = int(rng.integers(1, 40)); eps = float(rng.choice([0.0, 0.001, 0.03]))
+    npts = int(rng.integers(1, 150))
+    pts = np.stack([np.column_stack([rng.uniform(0, w - 1, npts), rng.uniform(0, h - 1, npts)]) for _ in imgs]).astype(np.float32)
+    d_pts = torch.from_numpy(pts).to(cuda)
+    capi.corner_subpix(t, d_pts, None, win, zz, it, eps)
+    got = d_pts.cpu().numpy()
+    for i, im in enumerate(imgs):
+        ref = ora.corner_subpix(im, pts[i], win, zz, it, eps)
+        assert np.array_equal(got[i].view(np.uint32), ref.view(np.uint32)), f"subpix {w}x{h} win {win} zz {zz} it {it} eps {eps} frame {i}"
