@@ -202,3 +202,55 @@ def test_fuzz_preprocess_and_refine(cuda, case):
     for i, im in enumerate(imgs):
         ref = ora.corner_subpix(im, pts[i], win, zz, it, eps)
         assert np.array_equal(got[i].view(np.uint32), ref.view(np.uint32)), f"subpix {w}x{h} win {win} zz {zz} it {it} eps {eps} frame {i}"
+
+
+@pytest.mark.parametrize("case", range(6 * SCALE))
+def test_fuzz_fast_grid(cuda, case):
+    """Grid-bucketed FAST (OpenVINS-style) with random grids, budgets, distances and tracked points."""
+    import torch
+    rng = np.random.default_rng(7000 + case)
+    gx, gy = int(rng.integers(1, 9)), int(rng.integers(1, 7))
+    w, h = int(rng.integers(max(64, 12 * gx), 520)), int(rng.integers(max(48, 12 * gy), 320))
+    thr = int(rng.choice([7, 15, 20, 40])); n = int(rng.integers(1, 400)); d = int(rng.choice([1, 3, 5, 10, 20]))
+    imgs = _images(rng, w, h, 2)
+    t = _dev(imgs, cuda)
+    nseed = int(rng.integers(0, 60))
+    seeds0 = np.column_stack([rng.uniform(0, w - 1, nseed), rng.uniform(0, h - 1, nseed)]).astype(np.float32)
+    sd = torch.zeros((2, 64, 2), dtype=torch.float32, device=cuda)
+    sd[0, :nseed] = torch.from_numpy(seeds0).to(cuda)
+    ns = torch.tensor([nseed, 0], dtype=torch.int32, device=cuda)
+    pts, sc, cnt = capi.fast_grid(t, thr, gx, gy, n, d, sd, ns)
+    pts, sc, cnt = pts.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+    for i, im in enumerate(imgs):
+        rxy, rsc = ora.fast_grid(im, thr, gx, gy, n, d, seeds0 if i == 0 else None)
+        tag = f"fast_grid {w}x{h} grid {gx}x{gy} thr {thr} n {n} d {d} seeds {nseed} frame {i}"
+        assert cnt[i] == len(rxy), f"{tag}: {cnt[i]} vs {len(rxy)}"
+        assert np.array_equal(pts[i, :cnt[i]], rxy) and np.array_equal(sc[i, :cnt[i]], rsc), tag
+
+
+@pytest.mark.parametrize("case", range(4 * SCALE))
+def test_fuzz_fundamental_ransac(cuda, case):
+    import torch
+    from two_view import two_view
+    rng = np.random.default_rng(8000 + case)
+    B = int(rng.integers(1, 5))
+    cap = int(rng.integers(8, 700))
+    p1 = np.zeros((B, cap, 2), np.float32); p2 = np.zeros((B, cap, 2), np.float32)
+    st = np.zeros((B, cap), np.uint8); n = np.zeros(B, np.int32)
+    for b in range(B):
+        x1, x2, _, _ = two_view(int(rng.integers(1, cap + 1)), float(rng.choice([0, 0.1, 0.3, 0.6])), float(rng.choice([0, 0.2, 0.5])),
+                                int(rng.integers(1, 1 << 20)))
+        n[b] = len(x1); p1[b, :n[b]] = x1; p2[b, :n[b]] = x2
+        st[b, :n[b]] = rng.random(n[b]) < float(rng.choice([1.0, 0.9, 0.5]))
+    thr = float(rng.choice([0.5, 1.0, 3.0])); conf = float(rng.choice([0.9, 0.99, 0.999])); iters = int(rng.choice([50, 300, 1000]))
+    seed = int(rng.integers(0, 1 << 31))
+    d_st = torch.from_numpy(st).to(cuda)
+    F, inl = capi.fundamental_ransac(torch.from_numpy(p1).to(cuda), torch.from_numpy(p2).to(cuda), d_st, torch.from_numpy(n).to(cuda),
+                                     thr, conf, iters, seed=seed)
+    F = F.cpu().numpy(); inl = inl.cpu().numpy(); got = d_st.cpu().numpy()
+    for b in range(B):
+        rF, rst, rc = ora.fundamental_ransac(p1[b, :n[b]], p2[b, :n[b]], st[b, :n[b]], thr, conf, iters, seed=seed)
+        tag = f"ransac b {b} n {n[b]} thr {thr} conf {conf} iters {iters} seed {seed}"
+        assert inl[b] == rc, f"{tag}: {inl[b]} vs {rc}"
+        assert np.array_equal(got[b, :n[b]], rst), tag
+        assert np.array_equal(F[b].view(np.uint64), rF.view(np.uint64)), tag
