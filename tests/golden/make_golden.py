@@ -67,6 +67,23 @@ def build():
     bgr = rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)
     g["bgr2gray"] = ora.bgr2gray(bgr)
     g["equalize_crc"] = np.array([crc(ora.equalize_hist(s0))], np.uint32)
+    # stages either side of the tracker
+    g["clahe_crc"] = np.array([crc(ora.clahe(s0, 10.0, 8, 8)), crc(ora.clahe(s0[:477, :750], 2.0, 4, 6)), crc(ora.clahe(nz, 0.0, 8, 8))],
+                              np.uint32)
+    g["subpix"] = ora.corner_subpix(s0, xy, 5, -1, 30, 0.01).view(np.uint32)
+    fwd, fst, _, back = ora.klt_track_bidir(s0, s1, xy, 0.04, 21, 2)
+    g["bidir_status"] = fst
+    g["bidir_back"] = back.view(np.uint32)
+    cam = (458.654, 457.296, 367.215, 248.375)
+    dist5 = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+    g["undistort"] = ora.undistort_points(xy, cam, dist5).view(np.uint32)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from two_view import two_view
+    x1, x2, _, _ = two_view(300, 0.25, 0.3, 21)
+    F, fmask, fcnt = ora.fundamental_ransac(x1, x2, None, 1.0, 0.99, 1000, seed=1234)
+    g["ransac_F"] = F.view(np.uint64)
+    g["ransac_mask"] = fmask
+    g["ransac_count"] = np.array([fcnt], np.int32)
     return g
 
 
