@@ -224,6 +224,30 @@ int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg* next_leve
                           int win, int max_iter, double eps, double min_eig_thr,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same step with the epipolar outlier filter of VINS-style front-ends (`F_threshold`, reference
+ * config/vins_mono.yaml:101) between tracking and refill: tracks that left the image are dropped, the rest is
+ * filtered by vfe_dev_fundamental_ransac on (previous, tracked) positions -- lifted to a virtual pinhole camera of
+ * focal length virtual_focal centred on the image when a calibration is given (what VINS-Mono's rejectWithF does with
+ * FOCAL_LENGTH 460), on raw pixel coordinates otherwise -- and only inliers survive.  Frames with fewer than 8 tracks
+ * are not filtered.  reject == NULL or f_threshold <= 0: exactly vfe_dev_frontend_step.  max_corners <= 2048. */
+typedef struct vfe_reject_opts {
+    double f_threshold;     /* pixels; <= 0 disables the filter */
+    double confidence;      /* 0.99 in VINS-Mono */
+    int max_iters;          /* 1..1024 */
+    unsigned seed;
+    const double* camera4;  /* fx, fy, cx, cy (host pointer) or NULL */
+    const double* dist5;    /* k1, k2, p1, p2, k3 (host pointer), required with camera4 */
+    double virtual_focal;   /* used with camera4 */
+    void* workspace;        /* vfe_reject_workspace(batch, max_corners) bytes, 256-byte aligned, device memory */
+    size_t workspace_bytes;
+} vfe_reject_opts;
+size_t vfe_reject_workspace(int batch, int max_corners);
+int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                                 float* pts, int* n_pts, int* n_tracked, int max_corners,
+                                 double quality, double min_distance,
+                                 int win, int max_iter, double eps, double min_eig_thr,
+                                 void* workspace, size_t workspace_bytes, const vfe_reject_opts* reject, void* stream);
+
 /* ---- kernel timing (HIP events recorded around every kernel the library launches) ------- */
 enum { VFE_K_PYR_DOWN = 0, VFE_K_GFTT_EIG, VFE_K_GFTT_SELECT, VFE_K_KLT, VFE_K_COMPACT, VFE_K_APPEND,
        VFE_K_FAST, VFE_K_ORB_RESIZE, VFE_K_ORB_BLUR, VFE_K_ORB_SELECT, VFE_K_ORB_DESC, VFE_K_MATCH,
@@ -337,6 +361,10 @@ int vfe_reset(vfe_ctx* ctx);
 #define VFE_EQ_HIST 1
 #define VFE_EQ_CLAHE 2
 int vfe_set_equalize(vfe_ctx* ctx, int mode);
+
+/* vfe_process_frame filters tracks with the epipolar constraint before refilling (see vfe_reject_opts):
+ * threshold <= 0 turns it off (default).  camera4 / dist5 may be NULL (raw pixel coordinates). */
+int vfe_set_f_rejection(vfe_ctx* ctx, double threshold, const double* camera4, const double* dist5, double virtual_focal);
 
 /* goodFeaturesToTrack on a host image (channels 1 or 3; 3 = BGR, converted on the GPU). */
 int vfe_detect_shi_tomasi(vfe_ctx* ctx, const uint8_t* data, int rows, int cols, size_t step, int channels,

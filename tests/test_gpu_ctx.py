@@ -165,6 +165,43 @@ def test_ctx_process_frame_stream(ctx):
     assert len(ctx.points()) == 0
 
 
+def test_ctx_process_frame_with_f_rejection(ctx):
+    """The same stream with VINS-Mono's rejectWithF switched on: tracks are lifted through the radtan model of
+    config/vins_mono.yaml:26-35 to a virtual pinhole camera (f = 460) and filtered at `F_threshold` before the refill."""
+    w, h, n, d, thr = 752, 480, 150, 30, 0.05
+    cam = (458.654, 457.296, 367.215, 248.375)
+    dist = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+
+    def lift(p):
+        u = ora.undistort_points(p, cam, dist).astype(np.float64)
+        return np.column_stack([460.0 * u[:, 0] + w / 2.0, 460.0 * u[:, 1] + h / 2.0]).astype(np.float32)
+    ctx.reset()
+    ctx.set_f_rejection(thr, cam, dist, 460.0)
+    try:
+        seq = [synth.scene(synth.BASE_SEED + 26, w, h, t) for t in range(4)]
+        ref, _ = ora.good_features(seq[0], n, 0.01, d)
+        ctx.process_frame(seq[0], 0, n, 0.01, d)
+        rejected = 0
+        for t in range(1, 4):
+            tr, det, tot = ctx.process_frame(seq[t], t * 50_000_000, n, 0.01, d)
+            nxt, st, _ = ora.klt_track(seq[t - 1], seq[t], ref, 21, 3)
+            r = np.rint(nxt)
+            keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < w - 1) & (r[:, 1] >= 1) & (r[:, 1] < h - 1)
+            _, mask, _ = ora.fundamental_ransac(lift(ref), lift(nxt), keep.astype(np.uint8), thr, 0.99, 1000, seed=0x5EED)
+            rejected += int(keep.sum() - mask.sum())
+            tracked = nxt[mask.astype(bool)]
+            ref = tracked
+            if n - len(tracked) > 0:
+                new, _ = ora.good_features(seq[t], n - len(tracked), 0.01, d, seeds=tracked)
+                ref = np.concatenate([tracked, new]) if len(new) else tracked
+            assert (tr, tot) == (len(tracked), len(ref))
+            assert np.array_equal(ctx.points().view(np.uint32), ref.view(np.uint32))
+        assert rejected > 0
+    finally:
+        ctx.set_f_rejection(0.0)
+        ctx.reset()
+
+
 def test_ctx_errors_do_not_throw(ctx):
     L = capi.lib()
     with pytest.raises(capi.VfeError):

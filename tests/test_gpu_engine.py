@@ -66,7 +66,8 @@ def test_orbslam3_state_machine_on_keypoint_counts(cuda, tmp_path):
 
 def test_vins_mono_stream_tracks_and_refills(cuda, tmp_path):
     """configs[0]: 752x480, 150 Shi-Tomasi corners (min_dist 30) + pyramidal KLT via vins_mono.yaml,
-    which also sets `equalize: 1`: every frame is histogram-equalised before detection and tracking."""
+    which also sets `equalize: 1` (every frame is histogram-equalised before detection and tracking) and
+    `F_threshold: 1.0` (tracks are filtered with the epipolar constraint before the refill)."""
     raw = [synth.scene(synth.BASE_SEED + 53, W, H, t) for t in range(4)]
     assert "equalize: 1" in VINS_YAML
     frames = [ora.equalize_hist(f) for f in raw]
@@ -80,6 +81,9 @@ def test_vins_mono_stream_tracks_and_refills(cuda, tmp_path):
             nxt, st, _ = ora.klt_track(frames[t - 1], f, ref, 21, 3)
             r = np.rint(nxt)
             keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < W - 1) & (r[:, 1] >= 1) & (r[:, 1] < H - 1)
+            # `F_threshold: 1.0`: epipolar filter on the surviving tracks (no camera.* keys in this file: raw pixels)
+            _, mask, _ = ora.fundamental_ransac(ref, nxt, keep.astype(np.uint8), 1.0, 0.99, 1000, seed=0x5EED)
+            keep = mask.astype(bool)
             tracked = nxt[keep]
             ref = tracked
             if 150 - len(tracked) > 0:

@@ -414,3 +414,69 @@ def test_frontend_step_many_streams_tile_order(cuda):
             r = ref[b % 3]
             assert n_pts[b] == len(r), f"t={t} b={b}: {n_pts[b]} vs {len(r)}"
             assert np.array_equal(pts[b, :n_pts[b]].view(np.uint32), r.view(np.uint32)), f"t={t} b={b}"
+
+
+def _oracle_reject(prev_pts, nxt, st, w, h, thr, camera=None, dist=None, focal=460.0, seed=0x5EED):
+    """Tracks that left the image are dropped, then the epipolar filter on (previous, tracked) positions."""
+    r = np.rint(nxt)
+    keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < w - 1) & (r[:, 1] >= 1) & (r[:, 1] < h - 1)
+    a, b = prev_pts, nxt
+    if camera is not None:
+        def lift(p):
+            u = ora.undistort_points(p, camera, dist).astype(np.float64)
+            return np.column_stack([focal * u[:, 0] + w / 2.0, focal * u[:, 1] + h / 2.0]).astype(np.float32)
+        a, b = lift(prev_pts), lift(nxt)
+    _, mask, _ = ora.fundamental_ransac(a, b, keep.astype(np.uint8), thr, 0.99, 1000, seed=seed)
+    return mask.astype(bool)
+
+
+@pytest.mark.parametrize("camera", [None, (458.654, 457.296, 367.215, 248.375)])
+def test_frontend_step_with_epipolar_filter(cuda, camera):
+    """`F_threshold` (config/vins_mono.yaml:101): the step with the epipolar filter between tracking and refill, on raw
+    pixels and through the undistorted virtual camera; some tracks are displaced by hand so that the filter has
+    something to reject, and the threshold is a twenty-fifth of a pixel (the synthetic motion is a plane moving rigidly, so every
+    honest track fits the geometry to within the tracker's own error).  Streams with fewer than 8 tracks are left alone."""
+    import torch
+    w, h, n, d, levels, q, thr = 752, 480, 150, 30, 3, 0.01, 0.04
+    dist = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+    seeds = [synth.BASE_SEED + 60, synth.BASE_SEED + 61, synth.BASE_SEED + 62]
+    seq = [[synth.scene(s, w, h, t) for t in range(3)] for s in seeds]
+    B = len(seq)
+    fe = capi.FrontendStep(B, h, w, n, levels, 21, quality=q, min_distance=d, device=cuda)
+    fe.set_f_rejection(thr, camera, dist if camera else None)
+    frames = [to_dev([seq[b][t] for b in range(B)], cuda) for t in range(3)]
+    pyr = [capi.alloc_pyramid(frames[0], levels), capi.alloc_pyramid(frames[0], levels)]
+    capi.build_pyramid(pyr[0])
+    ref = []
+    rng = np.random.default_rng(9)
+    for b in range(B):
+        xy, _ = ora.good_features(seq[b][0], n if b < 2 else 6, q, d)   # third stream: 6 tracks, never filtered
+        xy = xy.copy()
+        if b == 0:   # wrong previous positions for a few tracks: they still track somewhere, but off the epipolar geometry
+            bad = rng.choice(len(xy), 12, replace=False)
+            xy[bad] += rng.uniform(-6, 6, (12, 2)).astype(np.float32).round()
+        ref.append(xy)
+        fe.pts[b, :len(xy)] = torch.from_numpy(xy).to(cuda)
+        fe.n_pts[b] = len(xy)
+    cur, rejected = 0, 0
+    for t in range(1, 3):
+        nxt_slot = cur ^ 1
+        pyr[nxt_slot][0] = frames[t]
+        pts, n_pts, n_tr = fe.step(pyr[cur], pyr[nxt_slot])
+        cur = nxt_slot
+        pts, n_pts, n_tr = pts.cpu().numpy(), n_pts.cpu().numpy(), n_tr.cpu().numpy()
+        for b in range(B):
+            nx, st, _ = ora.klt_track(seq[b][t - 1], seq[b][t], ref[b], 21, levels - 1)
+            r = np.rint(nx)
+            inb = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < w - 1) & (r[:, 1] >= 1) & (r[:, 1] < h - 1)
+            keep = _oracle_reject(ref[b], nx, st, w, h, thr, camera, dist)
+            rejected += int(inb.sum() - keep.sum())
+            tracked = nx[keep]
+            cap_b = n
+            new = np.zeros((0, 2), np.float32)
+            if cap_b - len(tracked) > 0:
+                new, _ = ora.good_features(seq[b][t], cap_b - len(tracked), q, d, seeds=tracked)
+            ref[b] = np.concatenate([tracked, new]) if len(new) else tracked
+            assert n_tr[b] == len(tracked), f"t={t} b={b}: {n_tr[b]} vs {len(tracked)} tracked"
+            assert n_pts[b] == len(ref[b]) and np.array_equal(pts[b, :n_pts[b]].view(np.uint32), ref[b].view(np.uint32)), f"t={t} b={b}"
+    assert rejected >= 5, "the filter never rejected anything: the test does not exercise it"

@@ -35,6 +35,12 @@ ORB_KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", 
                          ("response", "<f4"), ("octave", "<i4"), ("lx", "<i4"), ("ly", "<i4")])
 
 
+class RejectOpts(C.Structure):
+    _fields_ = [("f_threshold", C.c_double), ("confidence", C.c_double), ("max_iters", C.c_int), ("seed", C.c_uint),
+                ("camera4", C.POINTER(C.c_double)), ("dist5", C.POINTER(C.c_double)), ("virtual_focal", C.c_double),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class Config(C.Structure):
     """struct vfe_config"""
     _fields_ = [("device", C.c_int), ("max_width", C.c_int), ("max_height", C.c_int), ("max_features", C.c_int),
@@ -74,6 +80,10 @@ SIGNATURES = {
     "vfe_dev_compact_tracks": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "vfe_dev_append_points": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "vfe_frontend_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfe_reject_workspace": (C.c_size_t, [C.c_int, C.c_int]),
+    "vfe_dev_frontend_step_reject": (C.c_int, [C.POINTER(DImg), C.POINTER(DImg), C.c_int, _P, _P, _P, C.c_int, C.c_double, C.c_double,
+                                               C.c_int, C.c_int, C.c_double, C.c_double, _P, C.c_size_t, _P, _P]),
+    "vfe_set_f_rejection": (C.c_int, [_P, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]),
     "vfe_dev_frontend_step": (C.c_int, [_DI, _DI, C.c_int, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int,
                                         C.c_int, C.c_double, C.c_double, _P, C.c_size_t, _P]),
     "vfe_prof_enable": (C.c_int, [C.c_int]),
@@ -332,10 +342,32 @@ class FrontendStep:
         self.n_pts = torch.zeros(batch, dtype=torch.int32, device=device)
         self.n_tracked = torch.zeros(batch, dtype=torch.int32, device=device)
 
+    def set_f_rejection(self, threshold, camera=None, dist=None, virtual_focal=460.0, confidence=0.99, max_iters=1000, seed=0x5EED):
+        """Epipolar outlier filter between tracking and refill (threshold <= 0 turns it off)."""
+        import torch
+        if not threshold or threshold <= 0:
+            self.reject = None
+            return
+        nbytes = lib().vfe_reject_workspace(self.batch, self.cap)
+        if nbytes == 0:
+            raise VfeError("vfe_reject_workspace: at most 2048 points per frame")
+        self.rj_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.pts.device)
+        self.rj_cam = (C.c_double * 4)(*camera) if camera is not None else None
+        self.rj_dist = (C.c_double * 5)(*dist) if camera is not None else None
+        self.reject = RejectOpts(float(threshold), float(confidence), int(max_iters), int(seed),
+                                 C.cast(self.rj_cam, C.POINTER(C.c_double)) if camera is not None else None,
+                                 C.cast(self.rj_dist, C.POINTER(C.c_double)) if camera is not None else None,
+                                 float(virtual_focal), self.rj_ws.data_ptr(), nbytes)
+
     def step(self, prev_levels, next_levels):
         n = self.nlevels
         pa = (DImg * n)(*[dimg(t) for t in prev_levels])
         na = (DImg * n)(*[dimg(t) for t in next_levels])
+        if getattr(self, "reject", None) is not None:
+            check(lib().vfe_dev_frontend_step_reject(pa, na, n, _ptr(self.pts), _ptr(self.n_pts), _ptr(self.n_tracked), self.cap,
+                                                     self.quality, self.min_distance, self.win, self.max_iter, self.eps,
+                                                     self.min_eig_thr, _ptr(self.ws), self.ws_bytes, C.byref(self.reject), _stream()))
+            return self.pts, self.n_pts, self.n_tracked
         check(lib().vfe_dev_frontend_step(pa, na, n, _ptr(self.pts), _ptr(self.n_pts), _ptr(self.n_tracked), self.cap,
                                           self.quality, self.min_distance, self.win, self.max_iter, self.eps,
                                           self.min_eig_thr, _ptr(self.ws), self.ws_bytes, _stream()))
@@ -524,6 +556,11 @@ class Context:
 
     def reset(self):
         check(lib().vfe_reset(self._h))
+
+    def set_f_rejection(self, threshold, camera=None, dist=None, virtual_focal=460.0):
+        cam = (C.c_double * 4)(*camera) if camera is not None else None
+        d5 = (C.c_double * 5)(*dist) if camera is not None else None
+        check(lib().vfe_set_f_rejection(self._h, float(threshold), cam, d5, float(virtual_focal)))
 
     def set_equalize(self, mode):
         """False/0 off, True/1 cv::equalizeHist, 2 or "clahe" CLAHE (clip 10, 8 x 8 tiles)."""

@@ -26,6 +26,7 @@ struct vfe_ctx {
     vfe_orb_kp* orb_kps; uint8_t* orb_desc; int orb_cap;
     void* mws; size_t mws_bytes;        /* growable: match descriptors + workspace */
     int cur, have_prev, w, h;           /* stream state */
+    double f_thr, f_cam[4], f_dist[5], f_focal; int f_have_cam; void* f_ws; size_t f_ws_bytes; /* epipolar track filter */
     int equalize; unsigned* eq_hist;    /* optional histogram equalisation of every uploaded frame */
     /* pinned host memory: frames are repacked here row by row and leave in ONE contiguous copy (a pitched
      * copy from pageable memory is done row by row by the runtime, ~4 ms per MB); results come back
@@ -102,6 +103,7 @@ extern "C" void vfe_destroy(vfe_ctx* c) {
     void* bufs[] = {c->bgr, c->pts, c->next_pts, c->corners, c->err, c->status, c->n_pts, c->n_tracked, c->counts,
                     c->ws, c->orb_kps, c->orb_desc, c->mws, c->eq_hist};
     for (void* p : bufs) (void)hipFree(p);
+    (void)hipFree(c->f_ws);
     (void)hipHostFree(c->h_stage[0]); (void)hipHostFree(c->h_stage[1]); (void)hipHostFree(c->h_io); (void)hipHostFree(c->h_small);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -179,6 +181,23 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
     CTX_TRY(hipStreamSynchronize(c->stream));
 #undef CTX_TRY
     *out = c;
+    return VFE_OK;
+}
+
+extern "C" int vfe_set_f_rejection(vfe_ctx* c, double threshold, const double* camera4, const double* dist5, double virtual_focal) {
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    if (!(threshold > 0)) { c->f_thr = 0; return VFE_OK; }
+    VFE_REQUIRE(c->cfg.max_features <= 2048, "the epipolar filter takes at most 2048 points: create the context with max_features <= 2048");
+    VFE_REQUIRE(!camera4 || (dist5 && virtual_focal > 0 && camera4[0] != 0.0 && camera4[1] != 0.0), "camera4 needs dist5 and a virtual focal length");
+    if (!c->f_ws) {
+        const size_t need = vfe_reject_workspace(1, c->cfg.max_features);
+        VFE_HIP(hipMalloc(&c->f_ws, need));
+        c->f_ws_bytes = need;
+    }
+    c->f_have_cam = camera4 ? 1 : 0;
+    if (camera4) { memcpy(c->f_cam, camera4, sizeof(c->f_cam)); memcpy(c->f_dist, dist5, sizeof(c->f_dist)); c->f_focal = virtual_focal; }
+    c->f_thr = threshold;
     return VFE_OK;
 }
 
@@ -338,8 +357,16 @@ extern "C" int vfe_process_frame(vfe_ctx* c, const uint8_t* data, int rows, int 
         VFE_HIP(hipMemsetAsync(c->n_tracked, 0, sizeof(int), c->stream));
     } else {
         ctx_levels(c, c->cur, cols, rows, c->cfg.pyramid_levels - 1, pl);
-        if ((rc = vfe_dev_frontend_step(pl, nl, nlev, c->pts, c->n_pts, c->n_tracked, max_corners, quality, min_distance,
-                                        c->cfg.win_size, 30, 0.01, 1e-4, c->ws, c->ws_bytes, c->stream))) return rc;
+        vfe_reject_opts rj;
+        memset(&rj, 0, sizeof(rj));
+        rj.f_threshold = c->f_thr; rj.confidence = 0.99; rj.max_iters = 1000; rj.seed = 0x5EEDu;
+        if (c->f_have_cam) { rj.camera4 = c->f_cam; rj.dist5 = c->f_dist; rj.virtual_focal = c->f_focal; }
+        rj.workspace = c->f_ws; rj.workspace_bytes = c->f_ws_bytes;
+        /* the filter works on arrays of max_features points, the capacity its workspace was sized for */
+        VFE_REQUIRE(!(c->f_thr > 0) || max_corners <= 2048, "the epipolar filter takes at most 2048 points");
+        if ((rc = vfe_dev_frontend_step_reject(pl, nl, nlev, c->pts, c->n_pts, c->n_tracked, max_corners, quality, min_distance,
+                                               c->cfg.win_size, 30, 0.01, 1e-4, c->ws, c->ws_bytes, c->f_thr > 0 ? &rj : nullptr,
+                                               c->stream))) return rc;
     }
     VFE_HIP(hipMemcpyAsync(&c->h_small[0], c->n_pts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VFE_HIP(hipMemcpyAsync(&c->h_small[1], c->n_tracked, sizeof(int), hipMemcpyDeviceToHost, c->stream));

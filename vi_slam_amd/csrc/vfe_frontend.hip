@@ -77,6 +77,76 @@ extern "C" int vfe_dev_append_points(float* pts, int* n_pts, int cap, int batch,
     return VFE_OK;
 }
 
+/* tracks that left the image (same rule as the compaction: rounded position inside [border, size - border)) */
+__global__ __launch_bounds__(256) void k_border_status(const float* __restrict__ pts, const int* __restrict__ n_pts, int cap, int W, int H,
+                                                       int border, uint8_t* __restrict__ status) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = n_pts ? max(0, min(n_pts[b], cap)) : cap;
+    if (i >= n) return;
+    const size_t o = (size_t)b * cap + i;
+    if (!status[o]) return;
+    const int ix = __float2int_rn(pts[2 * o]), iy = __float2int_rn(pts[2 * o + 1]);
+    if (!(ix >= border && ix < W - border && iy >= border && iy < H - border)) status[o] = 0;
+}
+
+/* normalised coordinates -> pixels of a virtual pinhole camera, in place */
+__global__ __launch_bounds__(256) void k_virtual_pinhole(float* __restrict__ pts, long long n, double f, double cx, double cy) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    pts[2 * i] = (float)(f * (double)pts[2 * i] + cx);
+    pts[2 * i + 1] = (float)(f * (double)pts[2 * i + 1] + cy);
+}
+
+struct RjWs { size_t u1_off, u2_off, F_off, inl_off, models_off, models_bytes, total; };
+static RjWs rj_layout(int batch, int cap) {
+    RjWs L; size_t o = 0;
+    L.u1_off = o; o += align_up((size_t)batch * cap * 2 * sizeof(float), 256);
+    L.u2_off = o; o += align_up((size_t)batch * cap * 2 * sizeof(float), 256);
+    L.F_off = o; o += align_up((size_t)batch * 9 * sizeof(double), 256);
+    L.inl_off = o; o += align_up((size_t)batch * sizeof(int), 256);
+    L.models_bytes = vfe_fundamental_workspace(batch);
+    L.models_off = o; o += align_up(L.models_bytes, 256);
+    L.total = o;
+    return L;
+}
+extern "C" size_t vfe_reject_workspace(int batch, int max_corners) {
+    if (batch <= 0 || max_corners <= 0 || max_corners > 2048) return 0;
+    return rj_layout(batch, max_corners).total;
+}
+
+static int fe_reject(const vfe_reject_opts* rj, const float* prev_pts, const float* next_pts, const int* n_pts, int cap, int batch,
+                     int w, int h, uint8_t* status, hipStream_t st) {
+    VFE_REQUIRE(cap <= 2048, "the epipolar filter takes at most 2048 points per frame");
+    VFE_REQUIRE(rj->workspace && (uintptr_t)rj->workspace % 256 == 0, "reject workspace must be 256-byte aligned");
+    VFE_REQUIRE(!rj->camera4 || rj->dist5, "camera4 needs dist5");
+    const RjWs L = rj_layout(batch, cap);
+    if (rj->workspace_bytes < L.total) {
+        vfe_set_error("reject workspace too small: need %zu bytes, got %zu", L.total, rj->workspace_bytes);
+        return VFE_E_NOMEM;
+    }
+    char* ws = (char*)rj->workspace;
+    int rc;
+    hipLaunchKernelGGL(k_border_status, dim3(div_up(cap, 256), batch), dim3(256), 0, st, next_pts, n_pts, cap, w, h, 1, status);
+    VFE_LAUNCH_CHECK();
+    const float* a = prev_pts;
+    const float* b = next_pts;
+    if (rj->camera4) {
+        VFE_REQUIRE(rj->virtual_focal > 0, "virtual_focal must be > 0");
+        float* u1 = (float*)(ws + L.u1_off);
+        float* u2 = (float*)(ws + L.u2_off);
+        const long long n = (long long)batch * cap;
+        if ((rc = vfe_dev_undistort_points(prev_pts, u1, n, rj->camera4, rj->dist5, st))) return rc;
+        if ((rc = vfe_dev_undistort_points(next_pts, u2, n, rj->camera4, rj->dist5, st))) return rc;
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_virtual_pinhole, dim3(blocks), dim3(256), 0, st, u1, n, rj->virtual_focal, w / 2.0, h / 2.0);
+        hipLaunchKernelGGL(k_virtual_pinhole, dim3(blocks), dim3(256), 0, st, u2, n, rj->virtual_focal, w / 2.0, h / 2.0);
+        VFE_LAUNCH_CHECK();
+        a = u1; b = u2;
+    }
+    return vfe_dev_fundamental_ransac(a, b, n_pts, cap, batch, status, rj->f_threshold, rj->confidence, rj->max_iters, rj->seed,
+                                      (double*)(ws + L.F_off), (int*)(ws + L.inl_off), ws + L.models_off, L.models_bytes, st);
+}
+
 struct FeWs { size_t gf_off, gf_bytes, next_off, status_off, corners_off, counts_off, order_off, total; };
 
 static FeWs fe_layout(int w, int h, int batch, int cap) {
@@ -124,6 +194,15 @@ extern "C" int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg
                                      double quality, double min_distance,
                                      int win, int max_iter, double eps, double min_eig_thr,
                                      void* workspace, size_t workspace_bytes, void* stream) {
+    return vfe_dev_frontend_step_reject(prev_levels, next_levels, nlevels, pts, n_pts, n_tracked, max_corners, quality, min_distance,
+                                        win, max_iter, eps, min_eig_thr, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                                            float* pts, int* n_pts, int* n_tracked, int max_corners,
+                                            double quality, double min_distance,
+                                            int win, int max_iter, double eps, double min_eig_thr,
+                                            void* workspace, size_t workspace_bytes, const vfe_reject_opts* reject, void* stream) {
     VFE_REQUIRE(prev_levels && next_levels && nlevels >= 1 && nlevels <= 8, "nlevels must be 1..8");
     VFE_REQUIRE(pts && n_pts && workspace, "NULL buffer");
     VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
@@ -159,6 +238,7 @@ extern "C" int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg
     if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, order, st))) return rc;
     if ((rc = klt_track_ordered(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
                                 win, max_iter, eps, min_eig_thr, 0, order, st))) return rc;
+    if (reject && reject->f_threshold > 0 && (rc = fe_reject(reject, pts, next_pts, n_pts, cap, batch, w, h, status, st))) return rc;
     if ((rc = vfe_dev_compact_tracks(next_pts, status, n_pts, cap, batch, w, h, 1, pts, n_pts, stream))) return rc;
     if (n_tracked) VFE_HIP(hipMemcpyAsync(n_tracked, n_pts, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (aux) {

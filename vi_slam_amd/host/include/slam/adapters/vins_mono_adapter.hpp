@@ -13,7 +13,12 @@ struct VINSMonoConfig {
     int maxCnt = 150;        /* max_cnt: features to keep */
     int minDist = 30;        /* min_dist: pixels between features */
     int freq = 10;
-    double fThreshold = 1.0; /* F_threshold: RANSAC threshold (not used by the front-end) */
+    double fThreshold = 1.0; /* F_threshold: epipolar RANSAC threshold in pixels of the virtual camera; <= 0: no filter */
+    /* camera.fx .. camera.cy, camera.k1 .. camera.p2 (config/vins_mono.yaml:26-35): with them the filter works on
+     * undistorted points lifted to a virtual pinhole camera of focal length 460, as VINS-Mono's rejectWithF does;
+     * without them on raw pixel coordinates */
+    double camera[4] = {0, 0, 0, 0};
+    double distortion[5] = {0, 0, 0, 0, 0};
     bool equalize = true;
     int pyramidLevels = 4;   /* upstream VINS-Mono calls calcOpticalFlowPyrLK with maxLevel 3 */
 };

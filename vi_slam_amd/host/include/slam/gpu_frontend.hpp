@@ -22,6 +22,9 @@ public:
     void setEqualize(bool on);
     /* VFE_EQ_NONE / VFE_EQ_HIST / VFE_EQ_CLAHE (`histogram_method`, docs/reference/15_openvins_smartphone_config.md:111) */
     void setEqualizeMode(int mode);
+    /* epipolar outlier filter between tracking and refill (`F_threshold`, config/vins_mono.yaml:101); threshold <= 0: off;
+     * camera4 / dist5 may be null (raw pixel coordinates) */
+    void setFRejection(double threshold, const double* camera4, const double* dist5, double virtualFocal);
     /* each returns false and records lastError() on failure; never throws */
     bool detectShiTomasi(const ImageView& img, int maxCorners, double quality, double minDistance, std::vector<float>& xy);
     bool orbExtract(const ImageView& img, int nFeatures, float scaleFactor, int nLevels, int fastThreshold,
@@ -38,6 +41,8 @@ private:
     vfe_ctx* ctx_ = nullptr;
     vfe_config cfg_{0, 0, 0, 1000, 4, 21, 0};
     int equalize_ = 0;
+    double fThr_ = 0, fCam_[4] = {0, 0, 0, 0}, fDist_[5] = {0, 0, 0, 0, 0}, fFocal_ = 460.0;
+    bool fHaveCam_ = false;
     std::string error_;
 };
 

@@ -13,7 +13,14 @@ namespace vi_slam {
 VINSMonoAdapter::VINSMonoAdapter() : AdapterBase({"VINSMono", false, false, false, 1e30, 1000, true}) {}
 VINSMonoAdapter::~VINSMonoAdapter() { shutdown(); }
 
-void VINSMonoAdapter::configKey(const std::string&, const std::string& key, const std::string& value) {
+void VINSMonoAdapter::configKey(const std::string& section, const std::string& key, const std::string& value) {
+    const std::string full = (section == "camera" && key.find('.') == std::string::npos) ? "camera." + key : key;
+    static const char* const camKeys[4] = {"camera.fx", "camera.fy", "camera.cx", "camera.cy"};
+    static const char* const distKeys[4] = {"camera.k1", "camera.k2", "camera.p1", "camera.p2"};
+    for (int i = 0; i < 4; i++) {
+        if (full == camKeys[i]) { config_.camera[i] = std::stod(value); return; }
+        if (full == distKeys[i]) { config_.distortion[i] = std::stod(value); return; }
+    }
     if (key == "image_width") config_.imageWidth = std::stoi(value);
     else if (key == "image_height") config_.imageHeight = std::stoi(value);
     else if (key == "max_cnt") config_.maxCnt = std::stoi(value);
@@ -27,6 +34,8 @@ void VINSMonoAdapter::configKey(const std::string&, const std::string& key, cons
 void VINSMonoAdapter::configDone() {
     frontEnd_.configure(std::max(config_.maxCnt, 1), config_.pyramidLevels, 21, 0);
     frontEnd_.setEqualize(config_.equalize);
+    const bool haveCamera = config_.camera[0] != 0.0 && config_.camera[1] != 0.0;
+    frontEnd_.setFRejection(config_.fThreshold, haveCamera ? config_.camera : nullptr, haveCamera ? config_.distortion : nullptr, 460.0);
 }
 
 int VINSMonoAdapter::feedImage(const ImageView& image, int64_t timestampNs, const std::vector<IMUSample>&) {

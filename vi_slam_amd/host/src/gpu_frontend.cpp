@@ -21,6 +21,17 @@ void GpuFrontEnd::setEqualizeMode(int mode) {
     if (ctx_) (void)vfe_set_equalize(ctx_, equalize_);
 }
 
+void GpuFrontEnd::setFRejection(double threshold, const double* camera4, const double* dist5, double virtualFocal) {
+    fThr_ = threshold > 0 ? threshold : 0;
+    fHaveCam_ = camera4 && dist5;
+    if (fHaveCam_) {
+        for (int i = 0; i < 4; i++) fCam_[i] = camera4[i];
+        for (int i = 0; i < 5; i++) fDist_[i] = dist5[i];
+        fFocal_ = virtualFocal;
+    }
+    if (ctx_) (void)vfe_set_f_rejection(ctx_, fThr_, fHaveCam_ ? fCam_ : nullptr, fHaveCam_ ? fDist_ : nullptr, fFocal_);
+}
+
 void GpuFrontEnd::release() {
     if (ctx_) { vfe_destroy(ctx_); ctx_ = nullptr; }
 }
@@ -39,6 +50,10 @@ bool GpuFrontEnd::ensure(const ImageView& img) {
     const int rc = vfe_create(&cfg_, &ctx_);
     if (rc != VFE_OK) { ctx_ = nullptr; return fail(rc); }
     (void)vfe_set_equalize(ctx_, equalize_);
+    if (fThr_ > 0) {
+        const int rcF = vfe_set_f_rejection(ctx_, fThr_, fHaveCam_ ? fCam_ : nullptr, fHaveCam_ ? fDist_ : nullptr, fFocal_);
+        if (rcF != VFE_OK) return fail(rcF);
+    }
     error_.clear();
     return true;
 }
