@@ -109,10 +109,13 @@ def test_fuzz_orb(cuda, case):
         assert np.array_equal(gd, rd), f"{tag}: descriptors"
 
 
-def _oracle_step(prev, cur, pts, n, q, d, levels, w, h):
+def _oracle_step(prev, cur, pts, n, q, d, levels, w, h, f_thr=0.0):
     nxt, st, _ = ora.klt_track(prev, cur, pts, 21, levels - 1)
     r = np.rint(nxt)
     keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < w - 1) & (r[:, 1] >= 1) & (r[:, 1] < h - 1)
+    if f_thr > 0:
+        _, mask, _ = ora.fundamental_ransac(pts, nxt, keep.astype(np.uint8), f_thr, 0.99, 1000, seed=0x5EED)
+        keep = mask.astype(bool)
     tracked = nxt[keep]
     if n - len(tracked) > 0:
         new, _ = ora.good_features(cur, n - len(tracked), q, d, seeds=tracked)
@@ -132,6 +135,8 @@ def test_fuzz_frontend_steps(cuda, case):
     seeds = [int(rng.integers(1, 1 << 30)) for _ in range(B)]
     seq = [[synth.scene(s, w, h, t) for t in range(3)] for s in seeds]
     fe = capi.FrontendStep(B, h, w, n, levels, 21, quality=q, min_distance=d, device=cuda)
+    f_thr = float(rng.choice([0.0, 0.0, 0.03, 0.2, 1.0]))   # epipolar filter between tracking and refill
+    fe.set_f_rejection(f_thr)
     frames = [_dev([seq[b][t] for b in range(B)], cuda) for t in range(3)]
     pyr = [capi.alloc_pyramid(frames[0], levels), capi.alloc_pyramid(frames[0], levels)]
     capi.build_pyramid(pyr[0])
@@ -151,8 +156,8 @@ def test_fuzz_frontend_steps(cuda, case):
         cur = nxt
         pts, n_pts, n_tr = pts.cpu().numpy(), n_pts.cpu().numpy(), n_tr.cpu().numpy()
         for b in range(B):
-            ref[b], ntr = _oracle_step(seq[b][t - 1], seq[b][t], ref[b], n, q, d, levels, w, h)
-            tag = f"{w}x{h} n {n} d {d} q {q} L{levels} t={t} b={b}"
+            ref[b], ntr = _oracle_step(seq[b][t - 1], seq[b][t], ref[b], n, q, d, levels, w, h, f_thr)
+            tag = f"{w}x{h} n {n} d {d} q {q} L{levels} F {f_thr} t={t} b={b}"
             assert n_tr[b] == ntr and n_pts[b] == len(ref[b]), f"{tag}: {n_tr[b]}/{n_pts[b]} vs {ntr}/{len(ref[b])}"
             assert np.array_equal(pts[b, :n_pts[b]].view(np.uint32), ref[b].view(np.uint32)), tag
 
