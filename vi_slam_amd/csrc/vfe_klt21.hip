@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 j++;
                 if (done || j == p.max_iter) {
                     /* last pass: only the residual at the final position, and only where it is reported */
-                    if (!(status && level == 0)) break;
+                    if (!(status && level == 0 && p.err)) break;
                     err_pass = true;
                     qx = outx - half; qy = outy - half;
                 } else { qx = nx; qy = ny; }
