@@ -54,7 +54,7 @@ def cpu_baseline(frames0, loss, budget_s=12.0):
     while t_used < budget_s and done < 200:
         cur = seq[order[i % len(order)]]
         t0 = time.perf_counter()
-        nxt, st, _ = ora.klt_track(prev, cur, pts, WIN, LEVELS - 1, fast=True)
+        nxt, st, _ = ora.klt_track(prev, cur, pts, WIN, LEVELS - 1, fast=True, want_err=False)  # the step reads no residuals
         r = np.rint(nxt)
         keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < W - 1) & (r[:, 1] >= 1) & (r[:, 1] < H - 1)
         tracked = nxt[keep]

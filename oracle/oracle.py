@@ -149,7 +149,7 @@ def good_features(img, max_corners, quality, min_distance, seeds=None, fast=Fals
 
 
 def klt_track(prev, nxt, pts, win=21, max_level=3, max_iter=30, eps=0.01, min_eig_thr=1e-4,
-              init=None, fast=False):
+              init=None, fast=False, want_err=True):
     prev, pp = _u8(prev)
     nxt, pn = _u8(nxt)
     h, w = prev.shape
@@ -163,7 +163,8 @@ def klt_track(prev, nxt, pts, win=21, max_level=3, max_iter=30, eps=0.01, min_ei
                                 C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint8),
                                 C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
     L.ora_klt_track(pp, pn, w, h, w, _p(pts, C.c_float), n, _p(out, C.c_float), _p(st, C.c_uint8),
-                    _p(err, C.c_float), win, max_level, max_iter, eps, min_eig_thr, 0 if init is None else 1)
+                    _p(err, C.c_float) if want_err else None, win, max_level, max_iter, eps, min_eig_thr,
+                    0 if init is None else 1)
     return out, st, err
 
 
