@@ -28,8 +28,12 @@
 template <int N> using ic = std::integral_constant<int, N>;
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-__device__ static inline float lane_up(float v) { return __shfl_up(v, 1); }     /* value of lane - 1 */
-__device__ static inline float lane_down(float v) { return __shfl_down(v, 1); } /* value of lane + 1 */
+/* neighbour lanes by DPP wave shifts (one VALU move each, no trip through the LDS crossbar); lane 0 / lane 63 get 0,
+ * which only halo lanes ever see */
+__device__ static inline u32 lane_up_u(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }   /* wave_shr:1 */
+__device__ static inline u32 lane_down_u(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); } /* wave_shl:1 */
+__device__ static inline float lane_up(float v) { return __uint_as_float(lane_up_u(__float_as_uint(v))); }     /* value of lane - 1 */
+__device__ static inline float lane_down(float v) { return __uint_as_float(lane_down_u(__float_as_uint(v))); } /* value of lane + 1 */
 
 /* sqrtf, correctly rounded, for x = 0 or x well inside the normal range (the sums of squares formed
  * here are 0 or > 1e-29): v_sqrt_f32 is within one ulp, the residuals against the two neighbouring
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
                 else if (dead_load) rC = 0;
                 else rC = (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
                           ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
-                const u32 l = (u32)__shfl_up((int)rC, 1), r = (u32)__shfl_down((int)rC, 1);
+                const u32 l = lane_up_u(rC), r = lane_down_u(rC);
                 const float fl = (float)(l >> 24), fr = (float)(r & 255u);
                 const float b0 = (float)(rC & 255u), b1 = (float)((rC >> 8) & 255u);
                 const float b2 = (float)((rC >> 16) & 255u), b3 = (float)(rC >> 24);
