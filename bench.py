@@ -6,7 +6,7 @@ One "step" = one steady-state front-end pass over one batch of independent synth
 all inputs resident in HBM before the timed region.  Streams are sharded across ranks with
 no data-path collective (weak scaling: `--batch` streams per GPU).
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
