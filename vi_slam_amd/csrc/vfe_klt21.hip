@@ -155,19 +155,25 @@ __device__ static inline void piece_template(const unsigned (&w)[4][3], unsigned
         vy[j] = as_u((D[j] + D[j + 2]) * (short)3 + D[j + 1] * (short)10);
         if (MASKED) { vx[j] &= m; vy[j] &= m; }
     }
-    int ix[NPX + 1], iy[NPX + 1];
+    int ix[NPX + 1], iy[NPX + 1], iv[NPX + 1];
 #pragma unroll
     for (int k = 0; k < NPX; k++) {
-        const int ival = dot2(P12[k + 1], W0, dot2(P12[k + 2], W1, 1 << 8)) >> 9;
+        iv[k] = dot2(P12[k + 1], W0, dot2(P12[k + 2], W1, 1 << 8)) >> 9;
         ix[k] = dot2(vx[k], W0, dot2(vx[k + 1], W1, 1 << 13)) >> 14;
         iy[k] = dot2(vy[k], W0, dot2(vy[k + 1], W1, 1 << 13)) >> 14;
         if (k >= 5 && k >= nvalid) { ix[k] = 0; iy[k] = 0; }
-        a11 += ix[k] * ix[k]; a12 += ix[k] * iy[k]; a22 += iy[k] * iy[k];
-        c1 += ival * ix[k]; c2 += ival * iy[k];
     }
-    ix[NPX] = 0; iy[NPX] = 0;
+    ix[NPX] = 0; iy[NPX] = 0; iv[NPX] = 0;
+    /* every value fits 16 bits (intensities <= 255 * 32, gradients <= 16 * 255): the Gram sums and the sums I*gx, I*gy
+     * take two pixels per instruction as dot products of the packed pairs */
 #pragma unroll
-    for (int k = 0; k < (NPX + 1) / 2; k++) { Tx[k] = pack16(ix[2 * k], ix[2 * k + 1]); Ty[k] = pack16(iy[2 * k], iy[2 * k + 1]); }
+    for (int k = 0; k < (NPX + 1) / 2; k++) {
+        const unsigned tx = pack16(ix[2 * k], ix[2 * k + 1]), ty = pack16(iy[2 * k], iy[2 * k + 1]);
+        const unsigned tv = pack16(iv[2 * k], iv[2 * k + 1]);
+        Tx[k] = tx; Ty[k] = ty;
+        a11 = dot2(tx, tx, a11); a12 = dot2(tx, ty, a12); a22 = dot2(ty, ty, a22);
+        c1 = dot2(tv, tx, c1); c2 = dot2(tv, ty, c2);
+    }
 }
 
 /* Bilinear-interpolated intensities (times 32) of a piece.  w[i] holds image rows y, y+1, bytes
