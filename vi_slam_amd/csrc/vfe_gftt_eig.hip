@@ -15,8 +15,8 @@
  * the element-wise stages run as packed fp32 operations (two pixels per instruction).  The
  * arithmetic (operation order, roundings, sign of the gradients where the product plane is a
  * reflection) is that of the CPU code, so results stay bit-exact: (float)(d - a) is formed as
- * float(d) - float(a), which is the same number, and the square root is the hardware estimate
- * corrected to the nearest float by the usual two residual tests.
+ * float(d) - float(a), which is the same number, and the square root is refined to the correctly
+ * rounded float.
  *
  * Local maxima above the running quality threshold are staged per wave in LDS and flushed with
  * one reservation atomic per batch of keys. */
@@ -28,23 +28,35 @@
 template <int N> using ic = std::integral_constant<int, N>;
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-/* neighbour lanes by DPP wave shifts (one VALU move each, no trip through the LDS crossbar); lane 0 / lane 63 get 0,
- * which only halo lanes ever see */
-__device__ static inline u32 lane_up_u(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }   /* wave_shr:1 */
-__device__ static inline u32 lane_down_u(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); } /* wave_shl:1 */
+/* neighbour lanes by DPP wave shifts (one VALU move each, no trip through the LDS crossbar); with bound_ctrl the lane
+ * shifted in from outside the wave (lane 0 / lane 63) reads 0, which only halo lanes ever see, and the move needs no
+ * prior value in its destination */
+__device__ static inline u32 lane_up_u(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }   /* wave_shr:1 */
+__device__ static inline u32 lane_down_u(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); } /* wave_shl:1 */
 __device__ static inline float lane_up(float v) { return __uint_as_float(lane_up_u(__float_as_uint(v))); }     /* value of lane - 1 */
 __device__ static inline float lane_down(float v) { return __uint_as_float(lane_down_u(__float_as_uint(v))); } /* value of lane + 1 */
 
-/* sqrtf, correctly rounded, for x = 0 or x well inside the normal range (the sums of squares formed
- * here are 0 or > 1e-29): v_sqrt_f32 is within one ulp, the residuals against the two neighbouring
- * floats decide.  For x = 0 the lower neighbour is a NaN pattern and both tests fail, leaving 0. */
-__device__ static inline float sqrt_rn(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
-    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
-    s = r_dn <= 0.f ? s_dn : s;
-    s = r_up > 0.f ? s_up : s;
-    return s;
+/* maximum of three floats as one instruction.  None of the values compared here can be a NaN, which the compiler
+ * cannot know: through fmaxf it quiets every operand first (v_max x, x) and rarely forms the three-operand maximum. */
+__device__ static inline float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+/* sqrtf of two values, correctly rounded, for x = 0 or x well inside the normal range (the sums of squares formed here
+ * are 0 or > 1e-29): hardware reciprocal square root, one coupled refinement of root and half-reciprocal, one residual
+ * step, all but the estimate as packed operations.  This is the compiler's own correctly rounded expansion for
+ * flushed-denormal mode; checked against sqrtf over every float in [2^-100, 2^100] (tools/exp_sqrt_rn.hip).  The
+ * estimate's argument is kept away from 0 so that x = 0 runs through as 0 rather than 0 * inf. */
+__device__ static inline f2 sqrt_rn2(f2 x) {
+    const f2 r = {__builtin_amdgcn_rsqf(fmaxf(x.x, 1e-36f)), __builtin_amdgcn_rsqf(fmaxf(x.y, 1e-36f))};
+    f2 s = x * r, h = r * 0.5f;
+    const f2 e = __builtin_elementwise_fma(-h, s, f2{0.5f, 0.5f});
+    h = __builtin_elementwise_fma(h, e, h);
+    s = __builtin_elementwise_fma(s, e, s);
+    const f2 d = __builtin_elementwise_fma(-s, s, x);
+    return __builtin_elementwise_fma(d, h, s);
 }
 
 template <bool WRITE_MAP, bool ALIGNED>
@@ -53,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
                                                   u32* __restrict__ cand_count, u64* __restrict__ cand, u32 seg_cap,
                                                   double quality) {
     __shared__ u64 s_stage[4][EV_STAGE];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* wave-uniform: row counters and addresses stay scalar */
     const unsigned wave = blockIdx.x * 4u + wv, nwaves = gridDim.x * 4u;
     const int W = img.w, H = img.h;
     const double scale = 1.0 / ((1 << 2) * 3 * 255.0);
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
                     const f2 a = sxx * 0.5f, cc = syy * 0.5f;
                     const f2 d = a - cc;
                     const f2 q = d * d + sxy * sxy;
-                    const f2 rt = {sqrt_rn(q.x), sqrt_rn(q.y)};
+                    const f2 rt = sqrt_rn2(q);
                     f2 e = (a + cc) - rt;
                     if (!yin) e = f2{-1.f, -1.f};
                     if (EDGE) {
@@ -184,8 +196,8 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
                 }
                 const f2 e01 = EG[s0][0], e23 = EG[s0][1];
                 const float l = lane_up(e23.y), r = lane_down(e01.x);
-                HM[s0][0] = f2{fmaxf(fmaxf(l, e01.x), e01.y), fmaxf(fmaxf(e01.x, e01.y), e23.x)};
-                HM[s0][1] = f2{fmaxf(fmaxf(e01.y, e23.x), e23.y), fmaxf(fmaxf(e23.x, e23.y), r)};
+                HM[s0][0] = f2{max3(l, e01.x, e01.y), max3(e01.x, e01.y, e23.x)};
+                HM[s0][1] = f2{max3(e01.y, e23.x, e23.y), max3(e23.x, e23.y, r)};
             }
             if constexpr (ST < 4) return;
             /* ---- output row N = yy - 3: value EG[s1], neighbourhood maxima HM[s2], HM[s1], HM[s0] ---- */
@@ -199,10 +211,10 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
                 }
                 return;
             }
-            wmax = fmaxf(wmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            wmax = max3(wmax, max3(v[0], v[1], v[2]), v[3]);
             if (N < 1 || N > H - 2) return;
-            const float m[4] = {fmaxf(fmaxf(HM[s2][0].x, HM[s1][0].x), HM[s0][0].x), fmaxf(fmaxf(HM[s2][0].y, HM[s1][0].y), HM[s0][0].y),
-                                fmaxf(fmaxf(HM[s2][1].x, HM[s1][1].x), HM[s0][1].x), fmaxf(fmaxf(HM[s2][1].y, HM[s1][1].y), HM[s0][1].y)};
+            const float m[4] = {max3(HM[s2][0].x, HM[s1][0].x, HM[s0][0].x), max3(HM[s2][0].y, HM[s1][0].y, HM[s0][0].y),
+                                max3(HM[s2][1].x, HM[s1][1].x, HM[s0][1].x), max3(HM[s2][1].y, HM[s1][1].y, HM[s0][1].y)};
             bool isc[4];
             bool any = false;
 #pragma unroll
