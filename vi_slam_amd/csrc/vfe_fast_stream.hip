@@ -92,7 +92,7 @@ __device__ static inline u32 fast_score_pair(const u32 (&R)[7][3], int t) {
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_stream(FastSet S, int threshold, int border, uint8_t* __restrict__ rowcnt, u32* __restrict__ tmp) {
     const int lane = threadIdx.x & 63;
-    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    const unsigned wave = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4u; /* wave-uniform */
     const unsigned total_work = S.item_begin[S.n];
     for (unsigned work = wave; work < total_work; work += nwaves) {
         int lv = 0;

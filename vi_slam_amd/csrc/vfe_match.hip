@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_match_batch(const u32* __restrict__ que
                                                      int* __restrict__ out_idx, int* __restrict__ out_dist, float ratio,
                                                      uint8_t* __restrict__ good) {
     __shared__ int s_i[4][64][2], s_d[4][64][2];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nq = min(max(nq_dev[b], 0), q_cap), nt = min(max(nt_dev[b], 0), t_cap);
     const int q = blockIdx.x * 64 + lane;
     const u32* qp = query + ((size_t)b * q_cap + min(q, q_cap - 1)) * 8;

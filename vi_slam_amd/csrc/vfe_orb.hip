@@ -437,7 +437,7 @@ __device__ static inline void sincos_det(float xf, float* s_out, float* c_out) {
 __global__ __launch_bounds__(256) void k_orb_desc(OrbLevels L, vfe_orb_kp* __restrict__ kps, uint8_t* __restrict__ desc,
                                                   const int* __restrict__ counts, int out_cap, int batch) {
     const int lane = threadIdx.x & 63;
-    const unsigned wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), nwaves = (gridDim.x * 256u) >> 6;
     const unsigned total = (unsigned)batch * (unsigned)out_cap;
     for (unsigned w = wave; w < total; w += nwaves) {
         const int b = w / (unsigned)out_cap, i = w - (unsigned)b * (unsigned)out_cap;

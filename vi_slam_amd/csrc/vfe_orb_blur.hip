@@ -35,7 +35,7 @@ struct BlurSet {
 
 __global__ __launch_bounds__(256) void k_orb_blur(BlurSet S) {
     const int lane = threadIdx.x & 63;
-    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    const unsigned wave = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4u; /* wave-uniform */
     const unsigned total_work = S.item_begin[S.n];
     const int band_h = S.band_h;
     for (unsigned work = wave; work < total_work; work += nwaves) {
