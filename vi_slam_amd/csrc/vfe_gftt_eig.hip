@@ -60,7 +60,7 @@ __device__ static inline f2 sqrt_rn2(f2 x) {
 }
 
 template <bool WRITE_MAP, bool ALIGNED>
-__global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
                                                   float* __restrict__ eigmap, u32* __restrict__ frame_max,
                                                   u32* __restrict__ cand_count, u64* __restrict__ cand, u32 seg_cap,
                                                   double quality) {
@@ -124,8 +124,9 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
 
         /* stc = how far the pipeline is filled: 1 row filters only, 2 + products, 3 + eigenvalues,
          * 4 + output */
-        auto step = [&](auto phc, auto stc, int t) {
+        auto step = [&](auto phc, auto stc, auto ybc, int t) {
             constexpr int ST = decltype(stc)::value;
+            constexpr bool YB = decltype(ybc)::value; /* the product or eigenvalue row of this step may lie outside the image */
             constexpr int s0 = decltype(phc)::value, s1 = (s0 + 2) % 3, s2 = (s0 + 1) % 3; /* newest, previous, oldest */
             const int yy = y0 - 3 + t;
             /* ---- image row yy (reflect-101): columns X0-1 .. X0+4 as floats, row filters ---- */
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
             /* ---- gradient products at row P = yy - 1 and their horizontal 3-sums ---- */
             {
                 const int P = yy - 1;
-                const bool yflip = (P == -1 || P == H);
+                const bool yflip = YB && (P == -1 || P == H);
                 f2 cv[3][2];
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
             /* ---- eigenvalue at row E = yy - 2 (sum rows E-1, E, E+1), and its horizontal 3-max ---- */
             {
                 const int E = yy - 2;
-                const bool yin = E >= 0 && E < H;
+                const bool yin = !YB || (E >= 0 && E < H);
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
                     const f2 sxx = (HS[s2][0][p] + HS[s1][0][p]) + HS[s0][0][p];
@@ -245,18 +246,25 @@ __global__ __launch_bounds__(256) void k_gftt_eig(DImg img, int strips_x, int ba
             }
         };
 
-        /* rows y0-3 .. y1+2: six steps fill the pipeline, then every step emits one output row */
-        step(ic<0>{}, ic<1>{}, 0); step(ic<1>{}, ic<1>{}, 1); step(ic<2>{}, ic<2>{}, 2);
-        step(ic<0>{}, ic<2>{}, 3); step(ic<1>{}, ic<3>{}, 4); step(ic<2>{}, ic<3>{}, 5);
-        const int T = 6 + (y1 - y0);
+        /* rows y0-3 .. y1+2: six steps fill the pipeline, then every step emits one output row.  Product and
+         * eigenvalue rows outside the image occur in the fill steps of the top band and in the last two steps of the
+         * bottom band only, so the steady-state loop carries no tests for them. */
+        constexpr std::true_type yb{};
+        constexpr std::false_type nyb{};
+        step(ic<0>{}, ic<1>{}, yb, 0); step(ic<1>{}, ic<1>{}, yb, 1); step(ic<2>{}, ic<2>{}, yb, 2);
+        step(ic<0>{}, ic<2>{}, yb, 3); step(ic<1>{}, ic<3>{}, yb, 4); step(ic<2>{}, ic<3>{}, yb, 5);
+        const int T = 6 + (y1 - y0), T_in = min(T, H + 4 - y0); /* steps t < T_in have rows P = yy-1 and E = yy-2 inside */
         int t0 = 6;
-        for (; t0 + 2 < T; t0 += 3) { /* whole triples only: a conditional step would keep the slot it replaces alive */
-            step(ic<0>{}, ic<4>{}, t0);
-            step(ic<1>{}, ic<4>{}, t0 + 1);
-            step(ic<2>{}, ic<4>{}, t0 + 2);
+        for (; t0 + 2 < T_in; t0 += 3) { /* whole triples only: a conditional step would keep the slot it replaces alive */
+            step(ic<0>{}, ic<4>{}, nyb, t0);
+            step(ic<1>{}, ic<4>{}, nyb, t0 + 1);
+            step(ic<2>{}, ic<4>{}, nyb, t0 + 2);
         }
-        if (t0 < T) step(ic<0>{}, ic<4>{}, t0);
-        if (t0 + 1 < T) step(ic<1>{}, ic<4>{}, t0 + 1);
+        /* at most two steps left of the loop's range and two beyond it */
+        if (t0 < T) step(ic<0>{}, ic<4>{}, yb, t0);
+        if (t0 + 1 < T) step(ic<1>{}, ic<4>{}, yb, t0 + 1);
+        if (t0 + 2 < T) step(ic<2>{}, ic<4>{}, yb, t0 + 2);
+        if (t0 + 3 < T) step(ic<0>{}, ic<4>{}, yb, t0 + 3);
         };
         if (edge_strip) item(std::true_type{}); else item(std::false_type{});
 
