@@ -17,7 +17,9 @@ HOST_SRCS = $(wildcard $(HOST)/src/*.cpp)
 HOST_HDRS = $(wildcard $(HOST)/include/*/*.hpp) $(wildcard $(HOST)/include/*/*/*.hpp) include/vfe.h
 CPP_TESTS = $(patsubst tests/cpp/%.cpp,tests/cpp/bin/%,$(wildcard tests/cpp/*.cpp))
 
-all: $(LIBDIR)/libvfe_synth.so $(LIBDIR)/libvfe.so $(LIBDIR)/libvi_slam_amd.so $(CPP_TESTS) oracle
+HIP_TESTS = $(patsubst tests/hip/%.hip,tests/cpp/bin/%,$(wildcard tests/hip/*.hip))
+
+all: $(LIBDIR)/libvfe_synth.so $(LIBDIR)/libvfe.so $(LIBDIR)/libvi_slam_amd.so $(CPP_TESTS) $(HIP_TESTS) oracle
 
 $(LIBDIR):
 	mkdir -p $(LIBDIR)
@@ -36,6 +38,11 @@ $(LIBDIR)/libvi_slam_amd.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/libvfe.so
 tests/cpp/bin/%: tests/cpp/%.cpp $(LIBDIR)/libvi_slam_amd.so
 	@mkdir -p tests/cpp/bin
 	$(CXX) -O1 -std=c++17 -Wall -I$(HOST)/include -Iinclude -o $@ $< -L$(LIBDIR) -lvi_slam_amd -lvfe -Wl,-rpath,'$$ORIGIN/../../../$(LIBDIR)' -lpthread
+
+# standalone device checks (plain main(), exit code 1 on a mismatch)
+tests/cpp/bin/%: tests/hip/%.hip $(HIP_HDRS)
+	@mkdir -p tests/cpp/bin
+	$(HIPCC) $(HIPFLAGS) -o $@ $<
 
 oracle:
 	$(MAKE) -C oracle libvfe_oracle.so

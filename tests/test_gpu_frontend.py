@@ -3,6 +3,8 @@
 Bar: bit-exact for pyramids, eigenvalue maps, corner lists; KLT positions are compared
 bit-exactly as well (the tolerance the front-end is held to is 1e-3 px).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -104,6 +106,37 @@ def test_min_eigen_map_bit_exact(cuda, w, h):
     for i, im in enumerate(imgs):
         r = ora.min_eigen_map(im)
         assert np.array_equal(e[i].view(np.uint32), r.view(np.uint32)), f"frame {i}: max abs diff {np.abs(e[i]-r).max()}"
+
+
+def test_packed_sqrt_correctly_rounded_everywhere(cuda):
+    """The eigenvalue kernel's square root against sqrtf for 0 and every float in [2^-100, 2^100] (1.7e9 values, on
+    the device; the program is built by `make` from tests/hip/check_sqrt_rn.hip)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "bin", "check_sqrt_rn")
+    assert os.path.exists(exe), "run `make` first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "packed rsq refinement 0" in r.stdout, r.stdout
+
+
+def test_eigen_pass_every_band_tail(cuda):
+    """The eigenvalue kernel walks bands of rows three at a time and finishes each band with up to four single steps,
+    the last two of the bottom band with the out-of-image rows: every height from 17 to 52 exercises every remainder,
+    bottom bands of 1..16 rows included (small batches use 16-row bands)."""
+    w = 300  # two strips, the second one a rim strip
+    for h in range(17, 53):
+        imgs = [synth.noise(100 + h, w, h), synth.scene(synth.BASE_SEED + h, w, h, 0)]
+        dev = to_dev(imgs, cuda)
+        e = capi.min_eigen_map(dev).cpu().numpy()
+        gf = capi.GoodFeatures(len(imgs), h, w, 300, device=cuda)
+        c, s, cnt = gf(dev, 0.01, 3)
+        c, s, cnt = c.cpu().numpy(), s.cpu().numpy(), cnt.cpu().numpy()
+        for i, im in enumerate(imgs):
+            assert np.array_equal(e[i].view(np.uint32), ora.min_eigen_map(im).view(np.uint32)), f"h {h} frame {i}"
+            rxy, rsc = ora.good_features(im, 300, 0.01, 3)
+            assert cnt[i] == len(rxy), f"h {h} frame {i}: {cnt[i]} vs {len(rxy)}"
+            assert np.array_equal(c[i, :cnt[i]], rxy), f"h {h} frame {i}"
+            assert np.array_equal(s[i, :cnt[i]].view(np.uint32), rsc.view(np.uint32)), f"h {h} frame {i}"
 
 
 @pytest.mark.parametrize("w,h,n,q,d", [(752, 480, 150, 0.01, 30), (752, 480, 200, 0.01, 10), (640, 480, 200, 0.007, 10),

@@ -21,12 +21,12 @@
  * Local maxima above the running quality threshold are staged per wave in LDS and flushed with
  * one reservation atomic per batch of keys. */
 #include "vfe_gftt.h"
+#include "vfe_sqrt_rn.h"
 #include <type_traits>
 
 #define EV_STAGE 256
 
 template <int N> using ic = std::integral_constant<int, N>;
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 /* neighbour lanes by DPP wave shifts (one VALU move each, no trip through the LDS crossbar); with bound_ctrl the lane
  * shifted in from outside the wave (lane 0 / lane 63) reads 0, which only halo lanes ever see, and the move needs no
@@ -42,21 +42,6 @@ __device__ static inline float max3(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
-}
-
-/* sqrtf of two values, correctly rounded, for x = 0 or x well inside the normal range (the sums of squares formed here
- * are 0 or > 1e-29): hardware reciprocal square root, one coupled refinement of root and half-reciprocal, one residual
- * step, all but the estimate as packed operations.  This is the compiler's own correctly rounded expansion for
- * flushed-denormal mode; checked against sqrtf over every float in [2^-100, 2^100] (tools/exp_sqrt_rn.hip).  The
- * estimate's argument is kept away from 0 so that x = 0 runs through as 0 rather than 0 * inf. */
-__device__ static inline f2 sqrt_rn2(f2 x) {
-    const f2 r = {__builtin_amdgcn_rsqf(fmaxf(x.x, 1e-36f)), __builtin_amdgcn_rsqf(fmaxf(x.y, 1e-36f))};
-    f2 s = x * r, h = r * 0.5f;
-    const f2 e = __builtin_elementwise_fma(-h, s, f2{0.5f, 0.5f});
-    h = __builtin_elementwise_fma(h, e, h);
-    s = __builtin_elementwise_fma(s, e, s);
-    const f2 d = __builtin_elementwise_fma(-s, s, x);
-    return __builtin_elementwise_fma(d, h, s);
 }
 
 template <bool WRITE_MAP, bool ALIGNED>
