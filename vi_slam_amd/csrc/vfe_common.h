@@ -92,6 +92,12 @@ __host__ __device__ static inline int reflect101(int p, int n) {
     return p;
 }
 
+/* Neighbour lanes of a wave by DPP wave shifts (one VALU move each, no trip through the LDS crossbar).  With bound_ctrl
+ * the lane shifted in from outside the wave (lane 0 going up, lane 63 going down) reads 0 and the move needs no prior
+ * value in its destination; the streaming kernels keep those two lanes as halo, so nothing reads that 0. */
+__device__ static inline uint32_t lane_up_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }   /* value of lane - 1 (wave_shr:1) */
+__device__ static inline uint32_t lane_down_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); } /* value of lane + 1 (wave_shl:1) */
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 

@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 else c = (u32)row[min(max(X0, 0), W - 1)] | ((u32)row[min(max(X0 + 1, 0), W - 1)] << 8) |
                          ((u32)row[min(max(X0 + 2, 0), W - 1)] << 16) | ((u32)row[min(max(X0 + 3, 0), W - 1)] << 24);
                 R[PH][1] = c;
-                R[PH][0] = (u32)__shfl_up((int)c, 1);
-                R[PH][2] = (u32)__shfl_down((int)c, 1);
+                R[PH][0] = lane_up_u(c);
+                R[PH][2] = lane_down_u(c);
             }
             if constexpr (ST < 1) return;
             /* ---- scores of row N = yy - 3 ---- */
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     s23 = fast_score_pair<2, PH>(R, threshold) & smask[1];
                 }
                 SC[2][0] = s01; SC[2][1] = s23;
-                const u32 sl = (u32)__shfl_up((int)s23, 1) >> 16, sr = (u32)__shfl_down((int)s01, 1) & 0xFFFFu;
+                const u32 sl = lane_up_u(s23) >> 16, sr = lane_down_u(s01) & 0xFFFFu;
                 SC[2][2] = sl | (sr << 16);
             }
             if constexpr (ST < 2) return;

@@ -28,11 +28,6 @@
 
 template <int N> using ic = std::integral_constant<int, N>;
 
-/* neighbour lanes by DPP wave shifts (one VALU move each, no trip through the LDS crossbar); with bound_ctrl the lane
- * shifted in from outside the wave (lane 0 / lane 63) reads 0, which only halo lanes ever see, and the move needs no
- * prior value in its destination */
-__device__ static inline u32 lane_up_u(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }   /* wave_shr:1 */
-__device__ static inline u32 lane_down_u(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); } /* wave_shl:1 */
 __device__ static inline float lane_up(float v) { return __uint_as_float(lane_up_u(__float_as_uint(v))); }     /* value of lane - 1 */
 __device__ static inline float lane_down(float v) { return __uint_as_float(lane_down_u(__float_as_uint(v))); } /* value of lane + 1 */
 

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_orb_blur(BlurSet S) {
                 else if (dead_load) c = 0;
                 else c = (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
                          ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
-                const u32 l = (u32)__shfl_up((int)c, 1), r = (u32)__shfl_down((int)c, 1);
+                const u32 l = lane_up_u(c), r = lane_down_u(c);
                 /* bytes of columns X0-3 .. X0+6 are l1 l2 l3 c0 c1 c2 c3 r0 r1 r2 =: q0 .. q9; pixel k taps
                  * q[k] .. q[k+6].  Pair P[j] = (q[j], q[j+1]) serves pixels (0,1) as tap j and, as P[j+2],
                  * pixels (2,3) */
