@@ -217,7 +217,8 @@ size_t vfe_frontend_workspace(int width, int height, int batch, int max_corners)
  * pts [batch][max_corners][2] and n_pts [batch] are updated in place to the new point set
  * (tracked points first, in order, then new corners by descending score).
  * n_tracked [batch] (may be NULL) receives the number of surviving tracks.
- * This is the batched form of what the adapters do per processImage call. */
+ * This is the batched form of what the adapters do per processImage call (reference
+ * include/slam/i_slam_framework.hpp:63, src/slam/adapters/vins_mono_adapter.cpp:19-23, 109). */
 int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
                           float* pts, int* n_pts, int* n_tracked, int max_corners,
                           double quality, double min_distance,
@@ -366,28 +367,33 @@ int vfe_set_equalize(vfe_ctx* ctx, int mode);
  * threshold <= 0 turns it off (default).  camera4 / dist5 may be NULL (raw pixel coordinates). */
 int vfe_set_f_rejection(vfe_ctx* ctx, double threshold, const double* camera4, const double* dist5, double virtual_focal);
 
-/* goodFeaturesToTrack on a host image (channels 1 or 3; 3 = BGR, converted on the GPU). */
+/* goodFeaturesToTrack on a host image (channels 1 or 3; 3 = BGR, converted on the GPU): replaces the cvtColor +
+ * goodFeaturesToTrack pair of reference src/slam/adapters/openvins_adapter.cpp:72-80 and basalt_adapter.cpp:44-53. */
 int vfe_detect_shi_tomasi(vfe_ctx* ctx, const uint8_t* data, int rows, int cols, size_t step, int channels,
                           int max_corners, double quality, double min_distance,
                           float* corners_xy, int* n_out);
 
-/* calcOpticalFlowPyrLK between two host images. */
+/* calcOpticalFlowPyrLK between two host images (`use_klt: true`, reference config/openvins.yaml:26; the optical-flow
+ * keys of config/basalt.yaml:85-108). */
 int vfe_klt_track(vfe_ctx* ctx, const uint8_t* prev, const uint8_t* next, int rows, int cols, size_t step,
                   const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err,
                   int max_level, int max_iter, double eps, double min_eig_thr);
 
-/* ORB::detectAndCompute on a host image. */
+/* ORB::detectAndCompute on a host image: replaces reference src/slam/adapters/orbslam3_adapter.cpp:71-79. */
 int vfe_orb_extract(vfe_ctx* ctx, const uint8_t* data, int rows, int cols, size_t step, int channels,
                     int nfeatures, float scale_factor, int nlevels, int fast_threshold,
                     vfe_orb_kp* kps, uint8_t* desc, int cap, int* n_out);
 
-/* knnMatch(k=2) + ratio test on host descriptors. */
+/* knnMatch(k=2) + ratio test on host descriptors (`knn_ratio: 0.70`, reference
+ * docs/reference/15_openvins_smartphone_config.md:105). */
 int vfe_match_knn2(vfe_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt,
                    float ratio, int* idx, int* dist, uint8_t* good);
 
 /* One front-end step of a live stream: pyramid of the new frame, KLT from the previous
  * frame's points, refill with Shi-Tomasi corners up to max_corners.  The first frame after
- * create/reset only detects. */
+ * create/reset only detects.  This is the body of ISLAMFramework::processImage (reference
+ * include/slam/i_slam_framework.hpp:63) for a tracking front-end, which the reference leaves empty in
+ * src/slam/adapters/vins_mono_adapter.cpp:19-23. */
 int vfe_process_frame(vfe_ctx* ctx, const uint8_t* data, int rows, int cols, size_t step, int channels,
                       int64_t timestamp_ns, int max_corners, double quality, double min_distance,
                       vfe_frame_stats* stats);
