@@ -1,8 +1,8 @@
 /* Shi-Tomasi corner detection (cv::goodFeaturesToTrack semantics) for gfx950, batched.
  *
  * Two kernels per call:
- *  k_gftt_eig    one pass over the image: Sobel -> gradient products -> 3x3 box sums ->
- *                smaller eigenvalue, all staged through LDS tiles with halos; fused with the
+ *  k_gftt_eig    (vfe_gftt_eig.hip) one pass over the image: Sobel -> gradient products -> 3x3 box sums ->
+ *                smaller eigenvalue, marching down the rows with everything in registers; fused with the
  *                frame maximum (atomic) and 3x3 non-max suppression, so the float map never
  *                goes to HBM.  Local maxima are appended to a per-frame candidate list as
  *                64-bit keys (score bits << 32 | y << 16 | x: same order as the linear index).  Candidates that cannot pass
