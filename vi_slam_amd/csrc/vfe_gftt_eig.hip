@@ -102,6 +102,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 HS[i][0][p] = HS[i][1][p] = HS[i][2][p] = f2{0.f, 0.f};
             }
 
+        /* the lane's four pixels of image row yy (reflect-101) */
+        auto load_row = [&](int yy) -> u32 {
+            const uint8_t* row = ip + (size_t)reflect101(yy, H) * img.pitch;
+            if ((ALIGNED && !EDGE) || fast_load) return *reinterpret_cast<const uint32_t*>(row + X0);
+            if (dead_load) return 0u;
+            return (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
+                   ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
+        };
+        u32 pre = load_row(y0 - 3);
+
         /* stc = how far the pipeline is filled: 1 row filters only, 2 + products, 3 + eigenvalues,
          * 4 + output */
         auto step = [&](auto phc, auto stc, auto ybc, int t) {
@@ -111,12 +121,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int yy = y0 - 3 + t;
             /* ---- image row yy (reflect-101): columns X0-1 .. X0+4 as floats, row filters ---- */
             {
-                const uint8_t* row = ip + (size_t)reflect101(yy, H) * img.pitch;
-                u32 rC;
-                if ((ALIGNED && !EDGE) || fast_load) rC = *reinterpret_cast<const uint32_t*>(row + X0);
-                else if (dead_load) rC = 0;
-                else rC = (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
-                          ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
+                /* the row was requested a step ago; request the next one now (the row after the band's last is a
+                 * valid address too and never used) */
+                const u32 rC = pre;
+                pre = load_row(yy + 1);
                 const u32 l = lane_up_u(rC), r = lane_down_u(rC);
                 const float fl = (float)(l >> 24), fr = (float)(r & 255u);
                 const float b0 = (float)(rC & 255u), b1 = (float)((rC >> 8) & 255u);
