@@ -127,17 +127,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int i = 0; i < 3; i++) SC[i][0] = SC[i][1] = SC[i][2] = 0;
 
+        /* the lane's four pixels of image row yy; rows and columns outside the image are never part of a scored
+         * circle: clamp */
+        auto load_row = [&](int yy) -> u32 {
+            const uint8_t* row = ip + (size_t)min(max(yy, 0), H - 1) * img.pitch;
+            if (fast_load) return *reinterpret_cast<const uint32_t*>(row + X0);
+            return (u32)row[min(max(X0, 0), W - 1)] | ((u32)row[min(max(X0 + 1, 0), W - 1)] << 8) |
+                   ((u32)row[min(max(X0 + 2, 0), W - 1)] << 16) | ((u32)row[min(max(X0 + 3, 0), W - 1)] << 24);
+        };
+        u32 pre = load_row(y0 - 4);
+
         /* stc: 0 = load only, 1 = also score row yy - 3, 2 = also (if t >= 8) report row yy - 4 */
         auto step = [&](auto phc, auto stc, int t) {
             constexpr int PH = decltype(phc)::value, ST = decltype(stc)::value;
             const int yy = y0 - 4 + t;
             {
-                /* rows and columns outside the image are never part of a scored circle: clamp */
-                const uint8_t* row = ip + (size_t)min(max(yy, 0), H - 1) * img.pitch;
-                u32 c;
-                if (fast_load) c = *reinterpret_cast<const uint32_t*>(row + X0);
-                else c = (u32)row[min(max(X0, 0), W - 1)] | ((u32)row[min(max(X0 + 1, 0), W - 1)] << 8) |
-                         ((u32)row[min(max(X0 + 2, 0), W - 1)] << 16) | ((u32)row[min(max(X0 + 3, 0), W - 1)] << 24);
+                /* the row was requested a step ago; request the next one now (clamped: always a valid address) */
+                const u32 c = pre;
+                pre = load_row(yy + 1);
                 R[PH][1] = c;
                 R[PH][0] = lane_up_u(c);
                 R[PH][2] = lane_down_u(c);

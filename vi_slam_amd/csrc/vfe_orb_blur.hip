@@ -63,17 +63,24 @@ __global__ __launch_bounds__(256) void k_orb_blur(BlurSet S) {
 #pragma unroll
         for (int i = 0; i < 7; i++) HR[i][0] = HR[i][1] = 0;
 
+        /* the lane's four pixels of source row yy (reflect-101) */
+        auto load_row = [&](int yy) -> u32 {
+            const uint8_t* row = ip + (size_t)reflect101(yy, H) * src.pitch;
+            if (fast_load) return *reinterpret_cast<const uint32_t*>(row + X0);
+            if (dead_load) return 0u;
+            return (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
+                   ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
+        };
+        u32 pre = load_row(y0 - 3);
+
         /* stc: 1 = fill the ring only, 2 = also emit output row yy - 3 */
         auto step = [&](auto phc, auto stc, int t) {
             constexpr int ph = decltype(phc)::value, ST = decltype(stc)::value;
             const int yy = y0 - 3 + t;
             {
-                const uint8_t* row = ip + (size_t)reflect101(yy, H) * src.pitch;
-                u32 c;
-                if (fast_load) c = *reinterpret_cast<const uint32_t*>(row + X0);
-                else if (dead_load) c = 0;
-                else c = (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
-                         ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
+                /* the row was requested a step ago; request the next one now (always a valid address) */
+                const u32 c = pre;
+                pre = load_row(yy + 1);
                 const u32 l = lane_up_u(c), r = lane_down_u(c);
                 /* bytes of columns X0-3 .. X0+6 are l1 l2 l3 c0 c1 c2 c3 r0 r1 r2 =: q0 .. q9; pixel k taps
                  * q[k] .. q[k+6].  Pair P[j] = (q[j], q[j+1]) serves pixels (0,1) as tap j and, as P[j+2],
