@@ -68,6 +68,35 @@ __global__ __launch_bounds__(256) void k_merge(const int* __restrict__ in_idx, c
     out_dist[2 * q] = d0; out_dist[2 * q + 1] = d1;
 }
 
+/* The same merge with one wavefront per query, for many lists per query (the per-chunk partial lists of a large train
+ * set): the lanes take the lists round-robin -- consecutive lists of a query are consecutive in memory -- and their
+ * top-2 lists are merged by a butterfly.  The two smallest (dist, idx) pairs of a set do not depend on the order in
+ * which its members are visited, so the result is the one of the serial merge. */
+__global__ __launch_bounds__(256) void k_merge_wave(const int* __restrict__ in_idx, const int* __restrict__ in_dist,
+                                                    int nlists, int nq, int* __restrict__ out_idx, int* __restrict__ out_dist) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (q >= nq) return;
+    int d0 = NO_DIST, d1 = NO_DIST, i0 = NO_IDX, i1 = NO_IDX;
+    const int2* pi = reinterpret_cast<const int2*>(in_idx) + (size_t)q * nlists;
+    const int2* pd = reinterpret_cast<const int2*>(in_dist) + (size_t)q * nlists;
+    for (int l = lane; l < nlists; l += 64) {
+        const int2 i = pi[l], d = pd[l];
+        if (i.x >= 0) top2_insert(d.x, i.x, d0, i0, d1, i1);
+        if (i.y >= 0) top2_insert(d.y, i.y, d0, i0, d1, i1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int pd0 = __shfl_xor(d0, o), pi0 = __shfl_xor(i0, o), pd1 = __shfl_xor(d1, o), pi1 = __shfl_xor(i1, o);
+        if (pi0 >= 0) top2_insert(pd0, pi0, d0, i0, d1, i1);
+        if (pi1 >= 0) top2_insert(pd1, pi1, d0, i0, d1, i1);
+    }
+    if (lane == 0) {
+        out_idx[2 * q] = i0; out_idx[2 * q + 1] = i1;
+        out_dist[2 * q] = d0; out_dist[2 * q + 1] = d1;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ratio(const int* __restrict__ idx, const int* __restrict__ dist, int nq,
                                                float ratio, uint8_t* __restrict__ good) {
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -163,8 +192,11 @@ extern "C" int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* t
     }
     VFE_LAUNCH_CHECK();
     ProfScope prof(VFE_K_MISC, st);
-    hipLaunchKernelGGL(k_merge, dim3((nq + 255) / 256), dim3(256), 0, st, part_idx, part_dist, (int)nchunks,
-                       (size_t)nchunks, (size_t)1, nq, out_idx, out_dist);
+    if (nchunks >= 16) /* a thread per query would walk its lists alone: a wave per query instead */
+        hipLaunchKernelGGL(k_merge_wave, dim3((nq + 3) / 4), dim3(256), 0, st, part_idx, part_dist, (int)nchunks, nq, out_idx, out_dist);
+    else
+        hipLaunchKernelGGL(k_merge, dim3((nq + 255) / 256), dim3(256), 0, st, part_idx, part_dist, (int)nchunks,
+                           (size_t)nchunks, (size_t)1, nq, out_idx, out_dist);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
