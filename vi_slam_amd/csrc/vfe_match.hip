@@ -22,6 +22,48 @@ __device__ static inline void top2_insert(int d, int i, int& d0, int& i0, int& d
     else if (d < d1 || (d == d1 && i < i1)) { d1 = d; i1 = i; }
 }
 
+/* Top-2 of the train rows [0, n) at `tr` (n <= 65536, wave-uniform address: scalar loads) for the query in a[]: the
+ * running pair is kept as two keys dist << 16 | row, so that the lexicographic (dist, row) order -- the order of one
+ * ascending scan with strict '<' -- is the integer order and an update is a median and a minimum. */
+#define KEY_NONE 0x7fffffffu
+#define SCAN_MAX_ROWS 65536
+struct Row8 { u32 w[8]; };
+/* d + popcount(x): the accumulating form, which the compiler trades for separate counts and three-operand adds */
+__device__ static inline u32 popc_acc(u32 x, u32 d) {
+    u32 r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(d));
+    return r;
+}
+__device__ static inline void top2_row(const u32 (&a)[8], const Row8& r, u32 t, u32& k0, u32& k1) {
+    u32 d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d = popc_acc(a[k] ^ r.w[k], d);
+    const u32 key = (d << 16) | t;
+    u32 m;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(k0), "v"(k1), "v"(key)); /* second smallest of the three */
+    k1 = m;
+    k0 = min(k0, key);
+}
+__device__ static inline void scan_top2(const u32 (&a)[8], const u32* __restrict__ tr, int n, u32& k0, u32& k1) {
+    k0 = k1 = KEY_NONE;
+    if (n <= 0) return;
+    /* the row after the one being compared is already on its way (the last row is requested twice) */
+    const Row8* rows = reinterpret_cast<const Row8*>(tr);
+    Row8 cur = rows[0];
+    int t = 0;
+    for (; t + 2 <= n; t += 2) {
+        const Row8 nx = rows[t + 1];
+        top2_row(a, cur, (u32)t, k0, k1);
+        cur = rows[min(t + 2, n - 1)];
+        top2_row(a, nx, (u32)t + 1u, k0, k1);
+    }
+    if (t < n) top2_row(a, cur, (u32)t, k0, k1);
+}
+__device__ static inline void key_decode(u32 key, int row0, int& d, int& i) {
+    d = key == KEY_NONE ? NO_DIST : (int)(key >> 16);
+    i = key == KEY_NONE ? NO_IDX : row0 + (int)(key & 0xFFFFu);
+}
+
 __global__ __launch_bounds__(MT_THREADS) void k_match(const u32* __restrict__ query, int nq,
                                                      const u32* __restrict__ train, long long nt, int chunk,
                                                      int nchunks, int base_index,
@@ -33,15 +75,11 @@ __global__ __launch_bounds__(MT_THREADS) void k_match(const u32* __restrict__ qu
     for (int k = 0; k < 8; k++) a[k] = (q < nq) ? query[(size_t)q * 8 + k] : 0u;
     const long long t0 = (long long)c * chunk;
     const long long t1 = (t0 + chunk < nt) ? t0 + chunk : nt;
-    int d0 = NO_DIST, d1 = NO_DIST, i0 = NO_IDX, i1 = NO_IDX;
-    for (long long t = t0; t < t1; t++) {
-        const u32* tr = train + (size_t)t * 8; /* wave-uniform address: scalar loads */
-        int d = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) d += __popc(a[k] ^ tr[k]);
-        if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = base_index + (int)t; }
-        else if (d < d1) { d1 = d; i1 = base_index + (int)t; }
-    }
+    u32 k0, k1;
+    scan_top2(a, train + (size_t)t0 * 8, (int)(t1 - t0), k0, k1); /* chunk <= SCAN_MAX_ROWS */
+    int d0, d1, i0, i1;
+    key_decode(k0, base_index + (int)t0, d0, i0);
+    key_decode(k1, base_index + (int)t0, d1, i1);
     if (q < nq) {
         const size_t o = ((size_t)q * nchunks + c) * 2;
         part_idx[o] = i0; part_idx[o + 1] = i1;
@@ -123,13 +161,14 @@ __global__ __launch_bounds__(256) void k_match_batch(const u32* __restrict__ que
     const int per = (nt + 3) / 4, t0 = wv * per, t1 = (int)blockIdx.x * 64 < nq ? min(t0 + per, nt) : t0;
     const u32* tb = train + (size_t)b * t_cap * 8;
     int d0 = NO_DIST, d1 = NO_DIST, i0 = NO_IDX, i1 = NO_IDX;
-    for (int t = t0; t < t1; t++) {
-        const u32* tr = tb + (size_t)t * 8; /* wave-uniform address: scalar loads */
-        int d = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) d += __popc(a[k] ^ tr[k]);
-        if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = t; }
-        else if (d < d1) { d1 = d; i1 = t; }
+    for (int ts = t0; ts < t1; ts += SCAN_MAX_ROWS) { /* one round unless the set is huge */
+        u32 k0, k1;
+        scan_top2(a, tb + (size_t)ts * 8, min(t1 - ts, SCAN_MAX_ROWS), k0, k1);
+        int d, i;
+        key_decode(k0, ts, d, i);
+        if (i >= 0) top2_insert(d, i, d0, i0, d1, i1);
+        key_decode(k1, ts, d, i);
+        if (i >= 0) top2_insert(d, i, d0, i0, d1, i1);
     }
     s_i[wv][lane][0] = i0; s_i[wv][lane][1] = i1; s_d[wv][lane][0] = d0; s_d[wv][lane][1] = d1;
     __syncthreads();
