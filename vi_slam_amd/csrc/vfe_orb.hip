@@ -87,44 +87,114 @@ __global__ void k_orb_tables(OrbTabs T) {
     T.tab[e][v] = (ofs << 9) | w1;
 }
 
-/* four horizontally adjacent output pixels per thread: 16 independent source loads in flight instead of 4.
- * xtab holds at least 4 * w4 entries (those past dst.w are not read as offsets). */
+/* RS_PX horizontally adjacent output pixels per thread, so that 4 * RS_PX independent source loads are in flight: a
+ * thread makes one round trip to memory in its life, and the kernel's rate is the bytes in flight per thread times the
+ * threads a CU holds, divided by that round trip.  xtab holds at least RS_PX * wn entries (those past dst.w are not read
+ * as offsets). */
+#define RS_PX 8
 __global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab,
-                                                    int w4, unsigned per_frame) {
+                                                    int wn, unsigned per_frame) {
     const unsigned id = blockIdx.x * 256u + threadIdx.x;
     const int b = blockIdx.y;
     if (id >= per_frame) return;
-    const int y = id / (unsigned)w4, x = 4 * (int)(id - (unsigned)y * (unsigned)w4);
-    uint4 t4 = *reinterpret_cast<const uint4*>(xtab + x);
-    if (x + 1 >= dst.w) t4.y = 0;
-    if (x + 2 >= dst.w) t4.z = 0;
-    if (x + 3 >= dst.w) t4.w = 0;
-    const u32 tx[4] = {t4.x, t4.y, t4.z, t4.w};
+    const int y = id / (unsigned)wn, x = RS_PX * (int)(id - (unsigned)y * (unsigned)wn);
+    u32 tx[RS_PX];
+#pragma unroll
+    for (int k = 0; k < RS_PX; k += 4) {
+        const uint4 t4 = *reinterpret_cast<const uint4*>(xtab + x + k);
+        tx[k] = t4.x; tx[k + 1] = t4.y; tx[k + 2] = t4.z; tx[k + 3] = t4.w;
+    }
+#pragma unroll
+    for (int k = 1; k < RS_PX; k++)
+        if (x + k >= dst.w) tx[k] = 0;
     const u32 ty = ytab[y];
     const int yo = ty >> 9;
     const u32 wy1 = ty & 511, wy0 = 256 - wy1;
     const uint8_t* r0 = src.frame(b) + (size_t)yo * src.pitch;
     const uint8_t* r1 = src.frame(b) + (size_t)min(yo + 1, src.h - 1) * src.pitch;
-    u32 p[4][4];
+    u32 p[RS_PX][4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < RS_PX; k++) {
         const int xo = tx[k] >> 9, x1 = min(xo + 1, src.w - 1);
         p[k][0] = r0[xo]; p[k][1] = r0[x1]; p[k][2] = r1[xo]; p[k][3] = r1[x1];
     }
-    u32 o[4];
+    u32 o[RS_PX];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < RS_PX; k++) {
         const u32 wx1 = tx[k] & 511, wx0 = 256 - wx1;
         const u32 h0 = p[k][0] * wx0 + p[k][1] * wx1;
         const u32 h1 = p[k][2] * wx0 + p[k][3] * wx1;
         o[k] = ((h0 * wy0 + h1 * wy1) + (1u << 15)) >> 16;
     }
     uint8_t* op = dst.frame(b) + (size_t)y * dst.pitch + x;
-    if (x + 3 < dst.w && ((dst.pitch | dst.fstride | (size_t)(uintptr_t)dst.data) & 3) == 0)
-        *reinterpret_cast<u32*>(op) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-    else {
+    if (x + RS_PX - 1 < dst.w && ((dst.pitch | dst.fstride | (size_t)(uintptr_t)dst.data) & 3) == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < RS_PX; k += 4)
+            *reinterpret_cast<u32*>(op + k) = o[k] | (o[k + 1] << 8) | (o[k + 2] << 16) | (o[k + 3] << 24);
+    } else {
+#pragma unroll
+        for (int k = 0; k < RS_PX; k++)
+            if (x + k < dst.w) op[k] = (uint8_t)o[k];
+    }
+}
+
+/* The same resize for 4-byte aligned sources and a scale factor of at most 2, with the gathers in LDS: the byte gathers
+ * of the kernel above go through the texture-address path at a handful of lanes per clock, which bounds it at about
+ * 1 TB/s.  A workgroup owns RS_SEG output pixels of one row: it copies the two source rows' span into LDS with
+ * coalesced dword loads, then every thread gathers its 4 * RS_PX taps from there. */
+#define RS_SEG (256 * RS_PX)
+#define RS_SPAN_DW (2 * RS_SEG / 4 + 4) /* dwords per staged source row */
+__global__ __launch_bounds__(256) void k_orb_resize_rows(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab) {
+    __shared__ u32 s_row[2][RS_SPAN_DW];
+    const int tid = threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int X0 = blockIdx.x * RS_SEG, xe = min(X0 + RS_SEG, dst.w) - 1; /* first and last output pixel of the workgroup */
+    const int s_lo = (int)(xtab[X0] >> 9) & ~3, s_hi = min((int)(xtab[xe] >> 9) + 1, src.w - 1);
+    const int ndw = min((s_hi - s_lo) / 4 + 1, RS_SPAN_DW);
+    const u32 ty = ytab[y];
+    const int yo = ty >> 9;
+    const u32 wy1 = ty & 511, wy0 = 256 - wy1;
+    const uint8_t* r0 = src.frame(b) + (size_t)yo * src.pitch + s_lo;
+    const uint8_t* r1 = src.frame(b) + (size_t)min(yo + 1, src.h - 1) * src.pitch + s_lo;
+    for (int i = tid; i < 2 * ndw; i += 256) {
+        const int row = i >= ndw ? 1 : 0, j = i - row * ndw;
+        s_row[row][j] = reinterpret_cast<const u32*>(row ? r1 : r0)[j];
+    }
+    __syncthreads();
+    const int x = X0 + RS_PX * tid;
+    if (x >= dst.w) return;
+    u32 tx[RS_PX];
+#pragma unroll
+    for (int k = 0; k < RS_PX; k += 4) {
+        const uint4 t4 = *reinterpret_cast<const uint4*>(xtab + x + k);
+        tx[k] = t4.x; tx[k + 1] = t4.y; tx[k + 2] = t4.z; tx[k + 3] = t4.w;
+    }
+#pragma unroll
+    for (int k = 1; k < RS_PX; k++)
+        if (x + k >= dst.w) tx[k] = tx[0];
+    const uint8_t* l0 = reinterpret_cast<const uint8_t*>(s_row[0]);
+    const uint8_t* l1 = reinterpret_cast<const uint8_t*>(s_row[1]);
+    u32 p[RS_PX][4];
+#pragma unroll
+    for (int k = 0; k < RS_PX; k++) {
+        const int xo = (int)(tx[k] >> 9), a0 = xo - s_lo, a1 = min(xo + 1, src.w - 1) - s_lo;
+        p[k][0] = l0[a0]; p[k][1] = l0[a1]; p[k][2] = l1[a0]; p[k][3] = l1[a1];
+    }
+    u32 o[RS_PX];
+#pragma unroll
+    for (int k = 0; k < RS_PX; k++) {
+        const u32 wx1 = tx[k] & 511, wx0 = 256 - wx1;
+        const u32 h0 = p[k][0] * wx0 + p[k][1] * wx1;
+        const u32 h1 = p[k][2] * wx0 + p[k][3] * wx1;
+        o[k] = ((h0 * wy0 + h1 * wy1) + (1u << 15)) >> 16;
+    }
+    uint8_t* op = dst.frame(b) + (size_t)y * dst.pitch + x;
+    if (x + RS_PX - 1 < dst.w && ((dst.pitch | dst.fstride | (size_t)(uintptr_t)dst.data) & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k < RS_PX; k += 4)
+            *reinterpret_cast<u32*>(op + k) = o[k] | (o[k + 1] << 8) | (o[k + 2] << 16) | (o[k + 3] << 24);
+    } else {
+#pragma unroll
+        for (int k = 0; k < RS_PX; k++)
             if (x + k < dst.w) op[k] = (uint8_t)o[k];
     }
 }
@@ -609,9 +679,15 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
         VFE_LAUNCH_CHECK();
         for (int l = 1; l < nlevels; l++) {
             const u32* xtab = (const u32*)(ws + W.xtab_off[l]); const u32* ytab = (const u32*)(ws + W.ytab_off[l]);
-            const int w4 = div_up(W.w[l], 4);
-            const unsigned per_frame = (unsigned)w4 * (unsigned)W.h[l];
-            hipLaunchKernelGGL(k_orb_resize, dim3((per_frame + 255) / 256, batch), dim3(256), 0, st, L.raw[l - 1], L.raw[l], xtab, ytab, w4, per_frame);
+            const int wn = div_up(W.w[l], RS_PX);
+            const unsigned per_frame = (unsigned)wn * (unsigned)W.h[l];
+            const DImg& sl = L.raw[l - 1];
+            const bool rows_ok = (((uintptr_t)sl.data | (uintptr_t)sl.pitch | (uintptr_t)sl.fstride) & 3) == 0 && sl.sub_n == 1 &&
+                                 W.w[l - 1] <= 2 * W.w[l] && W.h[l] <= 65535 && batch <= 65535;
+            if (rows_ok)
+                hipLaunchKernelGGL(k_orb_resize_rows, dim3(div_up(W.w[l], RS_SEG), W.h[l], batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab);
+            else
+                hipLaunchKernelGGL(k_orb_resize, dim3((per_frame + 255) / 256, batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab, wn, per_frame);
             VFE_LAUNCH_CHECK();
         }
     }
