@@ -97,6 +97,13 @@ def test_orb_bit_exact(cuda, w, h, nfeat):
     assert int(orb.counts[0]) > 0 and int(orb.counts[1]) > 0
 
 
+def test_orb_wide_frame(cuda):
+    """A frame wider than one resize workgroup's row segment (2048 output pixels): levels 1 and 2 are resized by
+    two workgroups per row."""
+    w, h = 3000, 96
+    check_orb(cuda, [synth.noise(29, w, h), synth.scene(synth.BASE_SEED + 8, w, h, 0)], 500)
+
+
 def test_orb_1080p_2000(cuda):
     w, h = 1920, 1080
     check_orb(cuda, [synth.scene(synth.BASE_SEED + 5, w, h, 0)], 2000)
