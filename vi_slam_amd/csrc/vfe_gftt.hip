@@ -103,9 +103,14 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
             if (rk[sg] != 0ull && f(rk[sg])) rk[sg] = 0ull;
             const u32 cn = s_segn[sg];
             u64* kp = keys + (size_t)sg * p.seg_cap;
-            for (u32 i = tid + SEL_THREADS; i < cn; i += SEL_THREADS) {
-                const u64 k = kp[i];
-                if (k != 0ull && f(k)) kp[i] = 0ull;
+            /* four loads in flight: one after the other, a busy segment costs a round trip to L2 per 1024 keys */
+            for (u32 i = tid + SEL_THREADS; i < cn; i += 4 * SEL_THREADS) {
+                u64 k[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) k[j] = i + j * SEL_THREADS < cn ? kp[i + j * SEL_THREADS] : 0ull;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (k[j] != 0ull && f(k[j])) kp[i + j * SEL_THREADS] = 0ull;
             }
         }
     };

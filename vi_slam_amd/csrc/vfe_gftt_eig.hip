@@ -43,7 +43,7 @@ template <bool WRITE_MAP, bool ALIGNED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
                                                   float* __restrict__ eigmap, u32* __restrict__ frame_max,
                                                   u32* __restrict__ cand_count, u64* __restrict__ cand, u32 seg_cap,
-                                                  double quality) {
+                                                  double quality, int band_mod, int band_sel) {
     __shared__ u64 s_stage[4][EV_STAGE];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* wave-uniform: row counters and addresses stay scalar */
     const unsigned wave = blockIdx.x * 4u + wv, nwaves = gridDim.x * 4u;
@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (unsigned work = wave; work < total_work; work += nwaves) {
         const int b = work % img.batch, t_item = work / img.batch;
         const int sxi = t_item % strips_x, byi = t_item / strips_x;
+        /* two-pass launches: this pass takes every band_mod-th band (band_sel != 0) or all the others */
+        if (band_mod > 0 && ((byi % band_mod == band_mod / 2) != (band_sel != 0))) continue;
         const int X0 = sxi * EV_OUT + 4 * (lane - 2); /* image column of this lane's pixel 0 */
         const int y0 = byi * band_h, y1 = min(y0 + band_h, H);
         const uint8_t* ip = img.frame(b);
@@ -283,13 +285,23 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
      * out through the dispatcher balances better than persistent waves with a fixed stride */
     dim3 grid(nblk < (1u << 20) ? nblk : (1u << 20));
     const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
-    if (eigmap)
+    if (eigmap) {
         hipLaunchKernelGGL((k_gftt_eig<true, false>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
-                           eigmap, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, 0u, 0.0);
-    else if (aligned)
-        hipLaunchKernelGGL((k_gftt_eig<false, true>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
-                           (float*)nullptr, frame_max, cand_count, cand, seg_cap, quality);
-    else
-        hipLaunchKernelGGL((k_gftt_eig<false, false>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
-                           (float*)nullptr, frame_max, cand_count, cand, seg_cap, quality);
+                           eigmap, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, 0u, 0.0, 0, 0);
+        return;
+    }
+    /* Candidates are pruned against the frame maximum seen so far.  When the whole launch fits on the chip at once
+     * every wave starts with a maximum of 0 and all local maxima become candidates (tens of thousands on a 1080p
+     * frame, of which a tenth survives the final threshold), which the selection kernel then pays for.  Such launches
+     * run in two passes: an eighth of the bands first, the others with the maximum those found. */
+    const bool two_pass = g.total <= 4096u && g.bands_y >= 8;
+    for (int pass = two_pass ? 1 : 0; pass >= 0; pass--) {
+        const int mod = two_pass ? 8 : 0;
+        if (aligned)
+            hipLaunchKernelGGL((k_gftt_eig<false, true>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+                               (float*)nullptr, frame_max, cand_count, cand, seg_cap, quality, mod, pass);
+        else
+            hipLaunchKernelGGL((k_gftt_eig<false, false>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+                               (float*)nullptr, frame_max, cand_count, cand, seg_cap, quality, mod, pass);
+    }
 }
