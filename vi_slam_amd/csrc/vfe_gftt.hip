@@ -216,7 +216,9 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     u64 U = ~0ull; /* exclusive upper bound of keys not yet consumed */
     u32 consumed = 0;
     int n_acc = 0;
-    u32 m_batch = SEL_M_FIRST;
+    /* a small refill rarely needs more than its few hundred best candidates: a quarter-size first batch sorts in a
+     * third of the time, and a further batch follows whenever the first does not fill the budget */
+    u32 m_batch = limit <= 64 ? SEL_M_FIRST / 4 : SEL_M_FIRST;
     while (consumed < total && n_acc < limit) {
         u64 T;
         if (total - consumed <= m_batch) {
