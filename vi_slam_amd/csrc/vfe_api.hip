@@ -46,26 +46,36 @@ extern "C" int vfe_device_count(int* count) {
 /* ---- kernel timing --------------------------------------------------------------------- */
 int g_vfe_prof_on = 0;
 namespace {
-struct ProfRec { int id; hipEvent_t a, b; };
+struct ProfRec { int id, dev; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_open;            /* begin recorded, end pending (per thread use is sequential) */
 std::vector<ProfRec> g_prof_done;
-std::vector<hipEvent_t> g_prof_pool;
+std::vector<std::vector<hipEvent_t>> g_prof_pool; /* spare events per device: an event belongs to the device it was created on */
 double g_prof_ms[VFE_K_COUNT];
 long long g_prof_n[VFE_K_COUNT];
-hipEvent_t prof_event() {
-    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+const size_t PROF_MAX_PENDING = 1u << 16;    /* nobody reading: stop recording rather than grow without bound */
+hipEvent_t prof_event(int dev) {
+    if ((size_t)dev < g_prof_pool.size() && !g_prof_pool[dev].empty()) {
+        hipEvent_t e = g_prof_pool[dev].back(); g_prof_pool[dev].pop_back(); return e;
+    }
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
+}
+void prof_recycle(int dev, hipEvent_t e) {
+    if (!e || dev < 0) return;
+    if ((size_t)dev >= g_prof_pool.size()) g_prof_pool.resize(dev + 1);
+    g_prof_pool[dev].push_back(e);
 }
 }  // namespace
 
 void vfe_prof_begin(int id, hipStream_t st) {
     std::lock_guard<std::mutex> g(g_prof_mu);
-    ProfRec r; r.id = id; r.a = prof_event(); r.b = prof_event();
-    if (!r.a || !r.b) return;
-    (void)hipEventRecord(r.a, st);
+    if (g_prof_done.size() >= PROF_MAX_PENDING) return;
+    ProfRec r; r.id = id; r.dev = 0;
+    if (hipGetDevice(&r.dev) != hipSuccess) return;
+    r.a = prof_event(r.dev); r.b = prof_event(r.dev);
+    if (!r.a || !r.b || hipEventRecord(r.a, st) != hipSuccess) { prof_recycle(r.dev, r.a); prof_recycle(r.dev, r.b); return; }
     g_prof_open.push_back(r);
 }
 void vfe_prof_end(int id, hipStream_t st) {
@@ -74,8 +84,8 @@ void vfe_prof_end(int id, hipStream_t st) {
         if (g_prof_open[i].id == id) {
             ProfRec r = g_prof_open[i];
             g_prof_open.erase(g_prof_open.begin() + i);
-            (void)hipEventRecord(r.b, st);
-            g_prof_done.push_back(r);
+            if (hipEventRecord(r.b, st) == hipSuccess) g_prof_done.push_back(r);
+            else { prof_recycle(r.dev, r.a); prof_recycle(r.dev, r.b); }
             return;
         }
 }
@@ -90,7 +100,7 @@ extern "C" int vfe_prof_read(double* ms, long long* launches, int reset) {
             r.id >= 0 && r.id < VFE_K_COUNT) {
             g_prof_ms[r.id] += t; g_prof_n[r.id] += 1;
         }
-        g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b);
+        prof_recycle(r.dev, r.a); prof_recycle(r.dev, r.b);
     }
     g_prof_done.clear();
     for (int i = 0; i < VFE_K_COUNT; i++) {
