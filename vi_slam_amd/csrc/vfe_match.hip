@@ -142,14 +142,16 @@ __global__ __launch_bounds__(256) void k_ratio(const int* __restrict__ idx, cons
     good[q] = (idx[2 * q] >= 0 && idx[2 * q + 1] >= 0 && (float)dist[2 * q] < ratio * (float)dist[2 * q + 1]) ? 1 : 0;
 }
 
-/* Batched frame-to-frame matching: workgroup (x, b) serves 64 queries of frame b; its four waves scan
- * a quarter of that frame's train rows each and merge their top-2 lists through LDS.  Set sizes come
+/* Batched frame-to-frame matching: workgroup (x, b) serves 64 queries of frame b; its MB_WAVES waves scan
+ * an equal share of that frame's train rows each and merge their top-2 lists through LDS (eight waves: 16 frame pairs of
+ * 2000 descriptors are then 4096 waves, four per SIMD, instead of two).  Set sizes come
  * from device memory, so extraction and matching can be queued back to back. */
-__global__ __launch_bounds__(256) void k_match_batch(const u32* __restrict__ query, const int* __restrict__ nq_dev, int q_cap,
+#define MB_WAVES 8
+__global__ __launch_bounds__(64 * MB_WAVES) void k_match_batch(const u32* __restrict__ query, const int* __restrict__ nq_dev, int q_cap,
                                                      const u32* __restrict__ train, const int* __restrict__ nt_dev, int t_cap,
                                                      int* __restrict__ out_idx, int* __restrict__ out_dist, float ratio,
                                                      uint8_t* __restrict__ good) {
-    __shared__ int s_i[4][64][2], s_d[4][64][2];
+    __shared__ int s_i[MB_WAVES][64][2], s_d[MB_WAVES][64][2];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nq = min(max(nq_dev[b], 0), q_cap), nt = min(max(nt_dev[b], 0), t_cap);
     const int q = blockIdx.x * 64 + lane;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void k_match_batch(const u32* __restrict__ que
 #pragma unroll
     for (int k = 0; k < 8; k++) a[k] = qp[k];
     /* workgroups past the last query only write the 'no neighbour' records */
-    const int per = (nt + 3) / 4, t0 = wv * per, t1 = (int)blockIdx.x * 64 < nq ? min(t0 + per, nt) : t0;
+    const int per = (nt + MB_WAVES - 1) / MB_WAVES, t0 = min(wv * per, nt), t1 = (int)blockIdx.x * 64 < nq ? min(t0 + per, nt) : t0;
     const u32* tb = train + (size_t)b * t_cap * 8;
     int d0 = NO_DIST, d1 = NO_DIST, i0 = NO_IDX, i1 = NO_IDX;
     for (int ts = t0; ts < t1; ts += SCAN_MAX_ROWS) { /* one round unless the set is huge */
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void k_match_batch(const u32* __restrict__ que
     if (wv == 0 && q < q_cap) {
         d0 = d1 = NO_DIST; i0 = i1 = NO_IDX;
 #pragma unroll
-        for (int w = 0; w < 4; w++)
+        for (int w = 0; w < MB_WAVES; w++)
 #pragma unroll
             for (int k = 0; k < 2; k++)
                 if (s_i[w][lane][k] >= 0) top2_insert(s_d[w][lane][k], s_i[w][lane][k], d0, i0, d1, i1);
@@ -265,7 +267,7 @@ extern "C" int vfe_dev_match_knn2_batch(const uint8_t* query, const int* nq, int
     VFE_REQUIRE(q_cap > 0 && t_cap > 0 && batch > 0 && batch <= 65535, "bad sizes");
     VFE_REQUIRE((uintptr_t)query % 4 == 0 && (uintptr_t)train % 4 == 0, "descriptors must be 4-byte aligned");
     ProfScope prof(VFE_K_MATCH, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_match_batch, dim3((q_cap + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_match_batch, dim3((q_cap + 63) / 64, batch), dim3(64 * MB_WAVES), 0, (hipStream_t)stream,
                        (const u32*)query, nq, q_cap, (const u32*)train, nt, t_cap, out_idx, out_dist, ratio, good);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
