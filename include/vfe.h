@@ -311,6 +311,20 @@ int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long 
                        int base_index, int* out_idx, int* out_dist,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* vfe_dev_match_knn2 for callers that cannot allocate device memory or bring a workspace: code under HIP graph
+ * capture, tight serving loops (one relocalisation query set after the other against a resident map), harnesses that
+ * forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, results and error behaviour as
+ * vfe_dev_match_knn2 minus the workspace: the per-chunk partial lists go to a VFE_MATCH_NOALLOC_BYTES array that the
+ * library's code object reserves on every GPU it runs on (held until the process ends).  The call enqueues its two
+ * kernels on `stream` and calls no allocating routine; a device's copy of the array is looked up once, by vfe_create
+ * or by the first call on that device (make that call before a graph capture).  Sizes whose partial lists do not fit
+ * (vfe_match_workspace(nq, nt) > VFE_MATCH_NOALLOC_BYTES: more than ~1 M queries, or tens of millions of train rows)
+ * are rejected with VFE_E_CAPACITY.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (different streams or threads) race; serialise them or use vfe_dev_match_knn2 with separate workspaces. */
+#define VFE_MATCH_NOALLOC_BYTES (16u << 20)
+int vfe_dev_match_knn2_noalloc(const uint8_t* query, int nq, const uint8_t* train, long long nt,
+                               int base_index, int* out_idx, int* out_dist, void* stream);
+
 /* The same for a batch of independent (query, train) pairs, e.g. the descriptors of consecutive frames
  * of `batch` streams as vfe_dev_orb_extract leaves them: set b has nq[b] (nt[b]) descriptors at
  * query + b*q_cap*32 (train + b*t_cap*32); nq and nt are DEVICE arrays, so extraction and matching can

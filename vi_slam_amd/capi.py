@@ -101,6 +101,7 @@ SIGNATURES = {
                                       C.c_size_t, _P]),
     "vfe_match_workspace": (C.c_size_t, [C.c_int, C.c_longlong]),
     "vfe_dev_match_knn2": (C.c_int, [_P, C.c_int, _P, C.c_longlong, C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "vfe_dev_match_knn2_noalloc": (C.c_int, [_P, C.c_int, _P, C.c_longlong, C.c_int, _P, _P, _P]),
     "vfe_dev_match_knn2_batch": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P]),
     "vfe_dev_merge_knn2": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "vfe_dev_ratio_test": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P]),
@@ -453,6 +454,22 @@ def match_knn2(query, train, base_index=0):
     dist = torch.empty((nq, 2), dtype=torch.int32, device=query.device)
     check(lib().vfe_dev_match_knn2(_ptr(query), nq, _ptr(train) if nt else None, nt, base_index, _ptr(idx), _ptr(dist),
                                    _ptr(ws), nbytes, _stream()))
+    return idx, dist
+
+
+MATCH_NOALLOC_BYTES = 16 << 20  # VFE_MATCH_NOALLOC_BYTES
+
+
+def match_knn2_noalloc(query, train, base_index=0, out=None):
+    """vfe_dev_match_knn2_noalloc: partial lists in the library's built-in scratch; `out` = (idx, dist) to reuse."""
+    import torch
+    nq, nt = query.shape[0], train.shape[0]
+    if out is None:
+        out = (torch.empty((nq, 2), dtype=torch.int32, device=query.device),
+               torch.empty((nq, 2), dtype=torch.int32, device=query.device))
+    idx, dist = out
+    check(lib().vfe_dev_match_knn2_noalloc(_ptr(query), nq, _ptr(train) if nt else None, nt, base_index, _ptr(idx), _ptr(dist),
+                                           _stream()))
     return idx, dist
 
 

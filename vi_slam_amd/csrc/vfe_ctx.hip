@@ -12,6 +12,7 @@
 #define CTX_MAX_LK_LEVELS 8
 
 extern "C" size_t vfe_match_workspace(int nq, long long nt);
+int vfe_match_scratch_init(void** out); /* vfe_match.hip: resolves this device's copy of the built-in match scratch */
 
 struct vfe_ctx {
     vfe_config cfg;
@@ -68,7 +69,10 @@ static int ctx_upload(vfe_ctx* c, int slot, const uint8_t* data, int rows, int c
     VFE_REQUIRE(channels == 1 || channels == 3, "channels must be 1 (gray) or 3 (BGR)");
     VFE_REQUIRE(cols <= c->cfg.max_width && rows <= c->cfg.max_height, "image larger than the context was created for");
     VFE_REQUIRE(step >= (size_t)cols * channels, "step smaller than a row");
-    /* repack into the pinned staging buffer with the device pitch, then one contiguous copy */
+    /* repack into the pinned staging buffer with the device pitch, then one contiguous copy.  Every successful call
+     * ends with a stream synchronisation, but an entry point that returned an error may have left a copy from this
+     * buffer in flight: wait for it before the buffer is overwritten (free when the stream is idle). */
+    VFE_HIP(hipStreamSynchronize(c->stream));
     uint8_t* hs = c->h_stage[slot & 1];
     const size_t row_bytes = (size_t)cols * channels;
     const size_t dpitch = channels == 1 ? (size_t)c->pitch[0] : (size_t)c->cfg.max_width * 3;
@@ -124,6 +128,18 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
     }
     VFE_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "device ordinal out of range");
     VFE_HIP(hipSetDevice(cfg->device));
+    {
+        /* the library carries gfx950 code objects only: on any other device the first launch would fail with a
+         * generic HIP error, so say so here */
+        hipDeviceProp_t prop;
+        VFE_HIP(hipGetDeviceProperties(&prop, cfg->device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            vfe_set_error("device %d is %s: this library is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+            return VFE_E_NODEVICE;
+        }
+        const int rcs = vfe_match_scratch_init(nullptr);
+        if (rcs != VFE_OK) return rcs;
+    }
     vfe_ctx* c = new (std::nothrow) vfe_ctx;
     if (!c) { vfe_set_error("out of host memory"); return VFE_E_NOMEM; }
     memset(c, 0, sizeof(*c));
@@ -248,8 +264,9 @@ extern "C" int vfe_klt_track(vfe_ctx* c, const uint8_t* prev, const uint8_t* nex
     VFE_REQUIRE(n >= 0 && n <= c->cfg.max_features, "n exceeds the context's max_features");
     VFE_REQUIRE(max_level >= 0 && max_level < c->cfg.pyramid_levels, "max_level exceeds the context's pyramid_levels");
     if (n == 0) return VFE_OK;
-    /* uses both slots: the stream's previous frame is forgotten */
+    /* uses both slots: the stream's previous frame and its tracks are forgotten, also when the call fails below */
     c->have_prev = 0;
+    VFE_HIP(hipMemsetAsync(c->n_pts, 0, sizeof(int), c->stream));
     if ((rc = ctx_upload(c, 0, prev, rows, cols, step, 1)) || (rc = ctx_upload(c, 1, next, rows, cols, step, 1))) return rc;
     vfe_dimg pl[CTX_MAX_LK_LEVELS], nl[CTX_MAX_LK_LEVELS];
     const int nlev = ctx_levels(c, 0, cols, rows, max_level, pl);
@@ -268,7 +285,6 @@ extern "C" int vfe_klt_track(vfe_ctx* c, const uint8_t* prev, const uint8_t* nex
     VFE_HIP(hipMemcpyAsync(o_pts, c->next_pts, pb, hipMemcpyDeviceToHost, c->stream));
     VFE_HIP(hipMemcpyAsync(o_st, c->status, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     VFE_HIP(hipMemcpyAsync(o_err, c->err, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    VFE_HIP(hipMemsetAsync(c->n_pts, 0, sizeof(int), c->stream));
     VFE_HIP(hipStreamSynchronize(c->stream));
     memcpy(next_pts, o_pts, pb);
     memcpy(status, o_st, (size_t)n);

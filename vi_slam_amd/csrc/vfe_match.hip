@@ -9,6 +9,7 @@
  * '<' (ties keep the lower train index).
  */
 #include "vfe_common.h"
+#include <mutex>
 
 typedef unsigned int u32;
 
@@ -207,23 +208,10 @@ extern "C" size_t vfe_match_workspace(int nq, long long nt) {
     return align_up((size_t)nq * nchunks * 2 * sizeof(int), 256) * 2;
 }
 
-extern "C" int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long long nt,
-                                  int base_index, int* out_idx, int* out_dist,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
-    VFE_REQUIRE(query && out_idx && out_dist && nq > 0, "NULL buffer or nq <= 0");
-    VFE_REQUIRE(nt >= 0 && (nt == 0 || train), "bad train set");
-    VFE_REQUIRE((long long)base_index + nt <= 0x7fffffffLL, "train indices overflow int");
-    VFE_REQUIRE((uintptr_t)query % 4 == 0 && (uintptr_t)train % 4 == 0, "descriptors must be 4-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    const int chunk = match_chunk(nq, nt);
-    const long long nchunks = nt > 0 ? (nt + chunk - 1) / chunk : 1;
-    VFE_REQUIRE(nchunks <= 65535, "train set too large for one call");
-    const size_t need = vfe_match_workspace(nq, nt);
-    if (!workspace || workspace_bytes < need) {
-        vfe_set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
-        return VFE_E_NOMEM;
-    }
-    VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+/* k_match over all (query block, chunk) pairs into the partial lists at `workspace` (vfe_match_workspace bytes), then
+ * the merge of every query's lists */
+static int match_launch(const uint8_t* query, int nq, const uint8_t* train, long long nt, int base_index,
+                        int* out_idx, int* out_dist, void* workspace, size_t need, int chunk, long long nchunks, hipStream_t st) {
     int* part_idx = (int*)workspace;
     int* part_dist = (int*)((char*)workspace + need / 2);
     {
@@ -240,6 +228,77 @@ extern "C" int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* t
                            (size_t)nchunks, (size_t)1, nq, out_idx, out_dist);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
+}
+
+static int match_check_args(const uint8_t* query, int nq, const uint8_t* train, long long nt, int base_index,
+                            const int* out_idx, const int* out_dist, int* chunk, long long* nchunks) {
+    VFE_REQUIRE(query && out_idx && out_dist && nq > 0, "NULL buffer or nq <= 0");
+    VFE_REQUIRE(nt >= 0 && (nt == 0 || train), "bad train set");
+    VFE_REQUIRE((long long)base_index + nt <= 0x7fffffffLL, "train indices overflow int");
+    VFE_REQUIRE((uintptr_t)query % 4 == 0 && (uintptr_t)train % 4 == 0, "descriptors must be 4-byte aligned");
+    *chunk = match_chunk(nq, nt);
+    *nchunks = nt > 0 ? (nt + *chunk - 1) / *chunk : 1;
+    VFE_REQUIRE(*nchunks <= 65535, "train set too large for one call");
+    return VFE_OK;
+}
+
+extern "C" int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long long nt,
+                                  int base_index, int* out_idx, int* out_dist,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    int chunk; long long nchunks;
+    const int rc = match_check_args(query, nq, train, nt, base_index, out_idx, out_dist, &chunk, &nchunks);
+    if (rc != VFE_OK) return rc;
+    const size_t need = vfe_match_workspace(nq, nt);
+    if (!workspace || workspace_bytes < need) {
+        vfe_set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+        return VFE_E_NOMEM;
+    }
+    VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+    return match_launch(query, nq, train, nt, base_index, out_idx, out_dist, workspace, need, chunk, nchunks, (hipStream_t)stream);
+}
+
+/* ---- the same search for callers that cannot allocate --------------------------------------------------------------
+ * The per-chunk partial lists live in a file-scope device array instead of a caller workspace.  Every GPU the library
+ * runs on holds its own copy of the array at its own address for the life of the process; the host-side name below is
+ * only a handle for hipGetSymbolAddress, never a device address, so every use goes through the per-device pointer
+ * resolved once (vfe_match_scratch_init, called by vfe_create and by the entry point's first call on a device).
+ * k_match writes every (query, chunk) slot the merge reads, so nothing has to be cleared between calls; calls that
+ * overlap on one GPU share the array and race. */
+static __device__ __align__(256) unsigned char scratch[VFE_MATCH_NOALLOC_BYTES];
+#define MATCH_MAX_DEVICES 64
+static void* g_scratch_ptr[MATCH_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+int vfe_match_scratch_init(void** out) {
+    int dev = -1;
+    VFE_HIP(hipGetDevice(&dev));
+    VFE_REQUIRE(dev >= 0 && dev < MATCH_MAX_DEVICES, "device ordinal beyond the scratch table");
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        VFE_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        VFE_REQUIRE(p && (uintptr_t)p % 256 == 0, "scratch symbol did not resolve to an aligned device address");
+        g_scratch_ptr[dev] = p;
+    }
+    if (out) *out = g_scratch_ptr[dev];
+    return VFE_OK;
+}
+
+extern "C" int vfe_dev_match_knn2_noalloc(const uint8_t* query, int nq, const uint8_t* train, long long nt,
+                                          int base_index, int* out_idx, int* out_dist, void* stream) {
+    int chunk; long long nchunks;
+    int rc = match_check_args(query, nq, train, nt, base_index, out_idx, out_dist, &chunk, &nchunks);
+    if (rc != VFE_OK) return rc;
+    const size_t need = vfe_match_workspace(nq, nt);
+    if (need > (size_t)VFE_MATCH_NOALLOC_BYTES) {
+        vfe_set_error("%d queries x %lld chunks need %zu bytes of partial lists, the built-in scratch holds %zu: "
+                      "use vfe_dev_match_knn2 with a workspace", nq, nchunks, need, (size_t)VFE_MATCH_NOALLOC_BYTES);
+        return VFE_E_CAPACITY;
+    }
+    void* ws = nullptr;
+    rc = vfe_match_scratch_init(&ws);
+    if (rc != VFE_OK) return rc;
+    return match_launch(query, nq, train, nt, base_index, out_idx, out_dist, ws, need, chunk, nchunks, (hipStream_t)stream);
 }
 
 extern "C" int vfe_dev_merge_knn2(const int* shard_idx, const int* shard_dist, int nshards, int nq,
