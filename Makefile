@@ -17,7 +17,7 @@ HOST_SRCS = $(wildcard $(HOST)/src/*.cpp)
 HOST_HDRS = $(wildcard $(HOST)/include/*/*.hpp) $(wildcard $(HOST)/include/*/*/*.hpp) include/vfe.h
 CPP_TESTS = $(patsubst tests/cpp/%.cpp,tests/cpp/bin/%,$(wildcard tests/cpp/*.cpp))
 
-HIP_TESTS = $(patsubst tests/hip/%.hip,tests/cpp/bin/%,$(wildcard tests/hip/*.hip))
+HIP_TESTS = $(patsubst tests/hip/%.hip,tests/cpp/bin/%,$(wildcard tests/hip/*.hip)) tests/cpp/bin/valu_ceiling
 
 all: $(LIBDIR)/libvfe_synth.so $(LIBDIR)/libvfe.so $(LIBDIR)/libvi_slam_amd.so $(CPP_TESTS) $(HIP_TESTS) oracle
 
@@ -27,8 +27,15 @@ $(LIBDIR):
 $(LIBDIR)/libvfe_synth.so: $(CSRC)/synth.cpp | $(LIBDIR)
 	$(CXX) -O2 -std=c++17 -fPIC -shared -o $@ $<
 
-$(LIBDIR)/libvfe.so: $(HIP_SRCS) $(HIP_HDRS) | $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+# one object per source so that `make -j` compiles them side by side (no device code is shared across files)
+OBJDIR = build/obj
+HIP_OBJS = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRCS))
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIBDIR)/libvfe.so: $(HIP_OBJS) | $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
 
 # host side: SLAMEngine + framework adapters (C++17), linked against libvfe.so next to it
 $(LIBDIR)/libvi_slam_amd.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/libvfe.so
@@ -43,6 +50,11 @@ tests/cpp/bin/%: tests/cpp/%.cpp $(LIBDIR)/libvi_slam_amd.so
 tests/cpp/bin/%: tests/hip/%.hip $(HIP_HDRS)
 	@mkdir -p tests/cpp/bin
 	$(HIPCC) $(HIPFLAGS) -o $@ $<
+
+# measurement tool: VALU issue ceiling per instruction class (tools/valu_ceiling.hip)
+tests/cpp/bin/valu_ceiling: tools/valu_ceiling.hip
+	@mkdir -p tests/cpp/bin
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
 
 oracle:
 	$(MAKE) -C oracle libvfe_oracle.so

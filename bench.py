@@ -1,16 +1,32 @@
 #!/usr/bin/env python3
 """Front-end throughput benchmark: frames/s at 1920x1080 with 1000 features.
 
-One "step" = one steady-state front-end pass over one batch of independent synthetic
-1080p streams per GPU (new-frame pyramid + 4-level KLT of <=1000 points + Shi-Tomasi refill),
-all inputs resident in HBM before the timed region.  Streams are sharded across ranks with
-no data-path collective (weak scaling: `--batch` streams per GPU).
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.
+One "step" of the headline leg = one steady-state front-end pass over one batch of independent synthetic 1080p
+streams per GPU (new-frame pyramid + 4-level KLT of <= 1000 points + Shi-Tomasi refill), all inputs resident in HBM
+before the timed region.  Streams are sharded across ranks with no data-path collective (weak scaling: `--batch`
+streams per GPU).  W untimed steps, then exactly K timed steps between barrier + synchronize pairs, the slowest rank
+counts.  The other configurations of the same front-end are measured in the same run and reported as sub-objects of
+the one JSON line rank 0 prints:
+
+    streams64      64 independent 1080p streams in total, 64 / N per GPU (strong scaling of the headline step)
+    orb_match      8-level ORB, 2000 keypoints per frame, + frame-to-frame kNN-2 / ratio test, `--orb-batch` streams per GPU
+    reloc          2000 query descriptors against a 10 M-descriptor map sharded over the ranks, per-shard top-2
+                   all-gathered (RCCL) and merged; planted near-duplicates are verified
+    single_stream  one live stream through the host-pointer API the framework adapters call (upload included),
+                   at 752x480 / 150 corners / 3 levels and at 1920x1080 / 1000 corners / 4 levels
+    cpu_baseline   the CPU oracle on the host cores of the same box: one thread (the reference's one-frame-at-a-time
+                   harness shape) and all cores (one independent stream per thread); N = 1 only
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its N ranks itself (a child
+`python -m torch.distributed.run`, started before anything in this process touches a GPU); under a launcher it is a rank.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,44 +38,103 @@ sys.path.insert(0, ROOT)
 W, H, NFEAT, LEVELS, WIN = 1920, 1080, 1000, 4, 21
 QUALITY, MIN_DIST = 0.01, 20.0
 HBM_PEAK_GBS = 8000.0
+ORB_NFEAT, ORB_LEVELS, ORB_SCALE, ORB_FAST_THR, KNN_RATIO = 2000, 8, 1.2, 20, 0.7
+MAP_ROWS, N_QUERIES = 10_000_000, 2000
+# VALU issue ceiling measured on this chip (tools/valu_ceiling.hip, profiles/r02_valu_ceiling.txt): packed 16-bit, dot2/dot4,
+# DPP, perm, med3, popcount, min/max and shifts occupy a SIMD's issue port for ~4.2 cycles per wave64 instruction at any
+# occupancy; only v_add/v_fma f32, v_add_u32, v_xor, v_mov reach ~2.2 with two or more waves per SIMD.
+VALU_CYCLES_PER_INST, SIMDS, CLOCK_GHZ = 4.2, 1024, 2.4
 
-# algorithmic bytes per 1080p frame (each distinct input byte once + each output byte once)
-BYTES_PYR = 2073600 + 518400 + 129600 + 32400              # read L0, write L1..L3
+# algorithmic bytes per 1080p frame (each distinct input byte once + each API-visible output byte once)
+BYTES_PYR = 2073600 + 518400 + 129600 + 32400               # read L0, write L1..L3
 BYTES_KLT = 2 * BYTES_PYR + NFEAT * 8 + NFEAT * (8 + 1 + 4)  # two pyramids + point I/O
 BYTES_DETECT = 2073600 + NFEAT * 8
+BYTES_FRAME = BYTES_PYR + BYTES_KLT + BYTES_DETECT
 ALGO_BYTES = {"k_pyr_down": BYTES_PYR, "k_klt": BYTES_KLT, "k_gftt_eig": 2073600, "k_gftt_select": NFEAT * 8,
               "k_compact": NFEAT * (8 + 1 + 8), "k_append": NFEAT * 16}
 
 
+def log(msg):
+    """Progress on stderr (stdout carries the one JSON line)."""
+    print(f"[bench r{os.environ.get('RANK', '0')} {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ launching ranks
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """Start n ranks of this script under torch.distributed.run and wait for them.  Runs before this process has
+    touched a GPU (device_count() only asks the driver how many there are)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} asked for, {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ synthetic inputs
+
 def make_frames(rank, batch, n_distinct, n_frames):
     """[n_frames][batch, H, W] uint8 host arrays; `n_distinct` seeded sequences tiled over the batch."""
+    from concurrent.futures import ThreadPoolExecutor
     from vi_slam_amd import synth
-    seqs = []
-    for s in range(n_distinct):
-        seed = synth.BASE_SEED + rank * 1000 + s
-        seqs.append([synth.scene(seed, W, H, t) for t in range(n_frames)])
+    def one_sequence(s):  # a thread renders all frames of a sequence: they share the generator's cached world
+        return [synth.scene(synth.BASE_SEED + rank * 1000 + s, W, H, t) for t in range(n_frames)]
+    with ThreadPoolExecutor(max_workers=host_cores()) as ex:  # the generator is native code and releases the GIL
+        seqs = list(ex.map(one_sequence, range(n_distinct)))
     return [np.stack([seqs[b % n_distinct][t] for b in range(batch)]) for t in range(n_frames)]
 
 
-def cpu_baseline(frames0, loss, budget_s=12.0):
-    """Reference-shaped CPU path (one frame at a time, one thread): LK between consecutive
-    frames + refill detection, timed on the CPU oracle built -O3 -march=native."""
+def host_cores():
+    """Cores this process may use: its affinity mask, capped by the box's thread budget when one is exported."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cap = os.environ.get("OMP_NUM_THREADS")
+    if cap and cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+
+def cpu_stream(seq, loss, budget_s, max_frames, fast=True):
+    """The reference-shaped CPU path for one stream (one frame at a time): LK between consecutive frames + refill
+    detection on the CPU oracle.  Returns (frames done, seconds inside the front-end calls)."""
     from oracle import oracle as ora
-    ora.build(fast=True)
-    seq = frames0
-    pts, _ = ora.good_features(seq[0], NFEAT, QUALITY, MIN_DIST, fast=True)
+    pts, _ = ora.good_features(seq[0], NFEAT, QUALITY, MIN_DIST, fast=fast)
     done, t_used, i = 0, 0.0, 0
     order = list(range(1, len(seq))) + list(range(len(seq) - 2, -1, -1))
     prev = seq[0]
-    while t_used < budget_s and done < 200:
+    while t_used < budget_s and done < max_frames:
         cur = seq[order[i % len(order)]]
         t0 = time.perf_counter()
-        nxt, st, _ = ora.klt_track(prev, cur, pts, WIN, LEVELS - 1, fast=True, want_err=False)  # the step reads no residuals
+        nxt, st, _ = ora.klt_track(prev, cur, pts, WIN, LEVELS - 1, fast=fast, want_err=False)  # the step reads no residuals
         r = np.rint(nxt)
         keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < W - 1) & (r[:, 1] >= 1) & (r[:, 1] < H - 1)
         tracked = nxt[keep]
         if NFEAT - len(tracked) > 0:
-            new, _ = ora.good_features(cur, NFEAT - len(tracked), QUALITY, MIN_DIST, seeds=tracked, fast=True)
+            new, _ = ora.good_features(cur, NFEAT - len(tracked), QUALITY, MIN_DIST, seeds=tracked, fast=fast)
             pts = np.concatenate([tracked, new]) if len(new) else tracked
         else:
             pts = tracked
@@ -68,18 +143,375 @@ def cpu_baseline(frames0, loss, budget_s=12.0):
         prev = cur
         done += 1
         i += 1
-    return {"value": done / t_used, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{done} consecutive 1920x1080 frames of one synthetic stream, {NFEAT} features, "
-                      f"{LEVELS}-level LK (pyramids rebuilt per call as calcOpticalFlowPyrLK does) + refill detect"}
+    return done, t_used
 
+
+def cpu_baseline(host, loss, n_distinct, budget_s=10.0):
+    """The CPU oracle (-O3 -march=native, built on this machine) on the same workload: (i) one thread, consecutive frames
+    of one stream -- the shape of the reference's E2E harness; (ii) one independent stream per host core."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as ora
+    ora.build(fast=True)
+    ora.lib(fast=True)
+    n_frames = len(host)
+    one_done, one_t = cpu_stream([host[t][0] for t in range(n_frames)], loss, budget_s, 200)
+    cores = host_cores()
+    seqs = [[host[t][c % n_distinct] for t in range(n_frames)] for c in range(cores)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:  # the oracle is native code behind ctypes: the GIL is released
+        res = list(ex.map(lambda s: cpu_stream(s, loss, budget_s, 200), seqs))
+    wall = time.perf_counter() - t0
+    all_done = sum(d for d, _ in res)
+    return {"value": all_done / wall, "unit": "frames/s", "cores": cores, "kind": "port",
+            "what": "this build's CPU restatement of the OpenCV calls (oracle/, -O3 -march=native), NOT OpenCV itself: "
+                    "OpenCV is not installed on this box",
+            "cpu_model": cpu_model(),
+            "one_core": {"value": one_done / one_t, "unit": "frames/s", "cores": 1,
+                         "sample": f"{one_done} consecutive 1920x1080 frames of one stream, one thread"},
+            "sample": f"{all_done} 1920x1080 frames: {cores} independent synthetic streams, one per core, each frame by frame "
+                      f"({NFEAT} features, {LEVELS}-level LK with pyramids rebuilt per call as calcOpticalFlowPyrLK does, refill "
+                      f"detect), {wall:.1f} s wall"}
+
+
+# ------------------------------------------------------------------------------------------------ timing helpers
+
+class Ranks:
+    def __init__(self, world, rank, dev, gloo):
+        self.world, self.rank, self.dev, self.gloo = world, rank, dev, gloo
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.gloo else self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.gloo else self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+
+def timed(rk, fn, steps, warmup):
+    """`warmup` untimed + exactly `steps` timed calls of fn between barrier + synchronize pairs; -> (seconds, the
+    slowest rank's; per-kernel HIP-event times of this rank inside the timed region)."""
+    import torch
+    from vi_slam_amd import capi
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    rk.barrier()
+    capi.prof_enable(True)
+    capi.prof_read(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    rk.barrier()
+    elapsed = time.perf_counter() - t0
+    capi.prof_enable(False)
+    prof = capi.prof_read(reset=True)
+    return rk.max_over_ranks(elapsed), prof
+
+
+def kernel_table(prof, elapsed, bytes_per_step, steps):
+    """Per kernel slot: launches, average launch duration (HIP events on the launch stream), share of the timed region,
+    algorithmic GB/s = algorithmic bytes per launch / average duration."""
+    out = {}
+    for name, (ms, n) in prof.items():
+        avg_ms = ms / n
+        per_launch = bytes_per_step.get(name, 0) * steps / max(n, 1)
+        out[name] = {"launches": int(n), "avg_ms": avg_ms, "share": ms / (elapsed * 1e3),
+                     "algo_bytes_per_launch": per_launch,
+                     "algo_GBs": per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 and per_launch else None}
+    return out
+
+
+def load_counters():
+    """Counter-derived figures of the committed rocprofv3 passes (tools/profile_round.sh): HBM bytes and VALU instructions
+    per launch, valid for the batch size they were taken at."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def roofline_for(kernels, counters, leg, batch):
+    """`roofline` object for the kernel with the largest share of the leg's timed region."""
+    scored = {k: v for k, v in kernels.items() if v["algo_GBs"]}
+    if not scored:
+        return None
+    dom = max(scored, key=lambda k: scored[k]["share"])
+    k = scored[dom]
+    roof = {"kernel": dom, "bound": "hbm", "achieved": k["algo_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": k["algo_GBs"] / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": k["algo_bytes_per_launch"],
+            "avg_launch_ms": k["avg_ms"]}
+    c = counters.get("legs", {}).get(leg, {})
+    if c.get("batch") == batch and dom in c.get("kernels", {}):
+        ck = c["kernels"][dom]
+        roof["traffic"] = ck.get("total_bytes")
+        roof["traffic_source"] = f"profiles/traffic.json ({counters.get('tag', '')})"
+        if ck.get("valu_insts"):
+            # instructions x measured issue cost against the SIMD cycles of the launch
+            rate = ck["valu_insts"] / (k["avg_ms"] * 1e-3)
+            peak = SIMDS * CLOCK_GHZ * 1e9 / VALU_CYCLES_PER_INST
+            roof["valu"] = {"achieved": rate / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": rate / peak,
+                            "insts_per_launch": ck["valu_insts"], "cycles_per_inst": VALU_CYCLES_PER_INST,
+                            "ceiling_source": "profiles/r02_valu_ceiling.txt"}
+            if rate / peak > 0.6 and roof["frac"] < 0.5:
+                roof["bound"] = "valu"
+                roof["note"] = ("achieved / peak / frac are against the HBM roof the metric names; what binds this kernel is "
+                                "VALU instruction issue, priced under 'valu'")
+    return roof
+
+
+# ------------------------------------------------------------------------------------------------ legs
+
+class FrontendLeg:
+    """Steady-state detect + track step over `batch` resident streams (the headline step and streams64)."""
+
+    def __init__(self, frames, batch, loss, dev):
+        import torch
+        from vi_slam_amd import capi
+        self.torch, self.capi = torch, capi
+        self.frames = [f[:batch] for f in frames]
+        self.B = batch
+        self.pyr = [capi.alloc_pyramid(self.frames[0], LEVELS), capi.alloc_pyramid(self.frames[0], LEVELS)]
+        self.fe = capi.FrontendStep(batch, H, W, NFEAT, LEVELS, WIN, quality=QUALITY, min_distance=MIN_DIST, device=dev)
+        # first frame of every stream: pyramid + initial detection (untimed)
+        self.cur = 0
+        self.pyr[0][0] = self.frames[0]
+        capi.build_pyramid(self.pyr[0])
+        gf = capi.GoodFeatures(batch, H, W, NFEAT, device=dev)
+        c, _, cnt = gf(self.frames[0], QUALITY, MIN_DIST)
+        self.fe.pts.copy_(c)
+        self.fe.n_pts.copy_(cnt)
+        del gf
+        nf = len(frames)
+        self.order = list(range(1, nf)) + list(range(nf - 2, -1, -1))
+        self.pos = 0
+        self.keep_den = 1000
+        self.keep_num = int(round((1.0 - min(max(loss, 0.0), 1.0)) * self.keep_den))
+
+    def drop_tracks(self):
+        """n <- floor(n * keep): the newest tracks of every stream are dropped (two element-wise torch kernels)."""
+        torch = self.torch
+        torch.mul(self.fe.n_pts, self.keep_num, out=self.fe.n_pts)
+        torch.div(self.fe.n_pts, self.keep_den, rounding_mode="floor", out=self.fe.n_pts)
+
+    def step(self):
+        nxt = self.cur ^ 1
+        self.pyr[nxt][0] = self.frames[self.order[self.pos % len(self.order)]]
+        self.fe.step(self.pyr[self.cur], self.pyr[nxt])
+        if self.keep_num < self.keep_den:
+            self.drop_tracks()
+        self.cur = nxt
+        self.pos += 1
+
+    def torch_kernels_ms(self, reps=50):
+        """Average duration of the track-loss arithmetic of one step (not a library kernel, so not in the HIP-event table)."""
+        torch = self.torch
+        saved = self.fe.n_pts.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self.drop_tracks()
+        e1.record()
+        torch.cuda.synchronize()
+        self.fe.n_pts.copy_(saved)
+        return e0.elapsed_time(e1) / reps
+
+
+def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg):
+    L = FrontendLeg(frames, batch, loss, rk.dev)
+    elapsed, prof = timed(rk, L.step, steps, warmup)
+    kernels = kernel_table(prof, elapsed, {k: v * batch for k, v in ALGO_BYTES.items()}, steps)
+    extra_ms = L.torch_kernels_ms() if L.keep_num < L.keep_den else 0.0
+    kernels["torch_track_loss"] = {"launches": 2 * steps, "avg_ms": extra_ms / 2, "share": extra_ms * steps / (elapsed * 1e3),
+                                   "algo_bytes_per_launch": 8 * batch, "algo_GBs": None,
+                                   "what": "n_pts <- floor(n_pts * keep): two element-wise torch kernels per step, timed apart"}
+    tracked = float(L.fe.n_tracked.float().mean().item())
+    points = float(L.fe.n_pts.float().mean().item())
+    return L, elapsed, kernels, roofline_for(kernels, counters, leg, batch), {"mean_tracked": tracked, "mean_points": points}
+
+
+def orb_level_pixels():
+    from ctypes import c_float, c_int
+    from vi_slam_amd import capi
+    wh = (c_int * (2 * ORB_LEVELS))()
+    sc = (c_float * ORB_LEVELS)()
+    assert capi.lib().vfe_orb_level_sizes(W, H, ORB_SCALE, ORB_LEVELS, wh, sc) == 0
+    return [wh[2 * i] * wh[2 * i + 1] for i in range(ORB_LEVELS)]
+
+
+def run_orb_match_leg(rk, frames, batch, steps, warmup, counters):
+    """configs[2]: per step, 8-level ORB (2000 keypoints) on a new frame of each of `batch` streams, then kNN-2 + ratio test
+    of its descriptors against those of the stream's previous frame."""
+    import torch
+    from vi_slam_amd import capi
+    fr = [f[:batch] for f in frames]
+    orb = [capi.Orb(batch, H, W, ORB_NFEAT, ORB_SCALE, ORB_LEVELS, ORB_FAST_THR, device=rk.dev) for _ in range(2)]
+    state = {"cur": 0, "pos": 0, "out": None}
+    nf = len(fr)
+    order = list(range(1, nf)) + list(range(nf - 2, -1, -1))
+    orb[0](fr[0])
+
+    def step():
+        nxt = state["cur"] ^ 1
+        orb[nxt](fr[order[state["pos"] % len(order)]])
+        state["out"] = capi.match_knn2_batch(orb[nxt].desc, orb[nxt].counts, orb[state["cur"]].desc, orb[state["cur"]].counts,
+                                             KNN_RATIO)
+        state["cur"] = nxt
+        state["pos"] += 1
+
+    elapsed, prof = timed(rk, step, steps, warmup)
+    px = orb_level_pixels()
+    nk = float(orb[state["cur"]].counts.float().mean().item())
+    good = float(state["out"][2].float().sum(dim=1).mean().item())
+    per_frame = {"k_orb_resize": px[0] + sum(px[1:]),           # read level 0, write levels 1..7
+                 "k_fast": sum(px) + 12 * nk,                    # read every level once, write (x, y, score) per keypoint
+                 "k_orb_blur": 2 * sum(px),                      # read + write every level
+                 "k_orb_select": 12 * nk + 32 * nk,              # FAST keypoints in, keypoint records out
+                 "k_orb_desc": 32 * nk + 32 * nk,                # keypoint records in, descriptors out (patch reads hit the blurred pyramid)
+                 "k_match": 32 * (2 * nk) + 16 * nk + nk}        # both descriptor sets in, top-2 lists + flags out
+    kernels = kernel_table(prof, elapsed, {k: v * batch for k, v in per_frame.items()}, steps)
+    total = rk.sum_over_ranks(batch * steps)
+    orb_bytes = px[0] + sum(px[1:]) + 2 * sum(px) + 64 * nk      # image in, pyramid out, blurred pyramid in + out, keypoints + descriptors out
+    return {"workload": f"configs[2]: 8-level ORB ({ORB_NFEAT} keypoints, 1.2/8/31/20) on 1920x1080 frames + frame-to-frame "
+                        f"Hamming kNN-2 with ratio {KNN_RATIO}, {batch} streams per GPU per step",
+            "value": total / elapsed, "unit": "frames/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "streams_per_gpu": batch, "mean_keypoints": nk, "mean_ratio_matches": good,
+            "algo_bytes_per_frame": orb_bytes + per_frame["k_match"],
+            "frac_of_hbm_roofline": total / elapsed / rk.world * (orb_bytes + per_frame["k_match"]) / (HBM_PEAK_GBS * 1e9),
+            "roofline": roofline_for(kernels, counters, "orb_match", batch), "kernels": kernels}
+
+
+def planted_position(i):
+    return (i * 4999 + 1234567) % MAP_ROWS  # 4999 is coprime to 10^7: distinct rows
+
+
+def verify_planted(q, idx, dist_):
+    """Known answers of the relocalisation leg.  Query i has a planted row (i % 21 flipped bits) at planted_position(i);
+    ORB queries can be near-duplicates of each other, so the expected neighbours of query i are the best two of ALL
+    planted rows by (distance, global row), computed here on the host from the 2000 x 2000 distances.  Unplanted rows are
+    uniform random bits (about 128 +- 8 bits away from anything; the closest of 10 M is ~85 bits away), so they cannot enter a
+    top-2 whose distances are below 60.  -> (all as expected, number of queries whose top-1 is their own planted row)."""
+    from vi_slam_amd import synth
+    n = len(q)
+    planted = np.stack([synth.flip_bits(i, q[i], i % 21) for i in range(n)])
+    pos = np.array([planted_position(i) for i in range(n)], np.int64)
+    q64, p64 = q.view(np.uint64), planted.view(np.uint64)
+    ok, own = True, 0
+    for i0 in range(0, n, 250):
+        d = np.bitwise_count(q64[i0:i0 + 250, None, :] ^ p64[None, :, :]).sum(axis=2).astype(np.int64)  # [250, n]
+        key = d * (1 << 32) + pos[None, :]
+        best = np.argsort(key, axis=1)[:, :2]
+        for r in range(d.shape[0]):
+            i = i0 + r
+            j0, j1 = best[r]
+            ok &= bool(idx[i, 0] == pos[j0] and dist_[i, 0] == d[r, j0])
+            if d[r, j1] < 60:
+                ok &= bool(idx[i, 1] == pos[j1] and dist_[i, 1] == d[r, j1])
+            own += int(idx[i, 0] == pos[i])
+    return ok, own
+
+
+def run_reloc_leg(rk, steps, warmup, counters):
+    """configs[4]: 2000 queries against a 10 M-row map, rows [shard_range(10 M, rank, world)) on this rank; per-shard
+    top-2 all-gathered and merged by (distance, global index).  Every query has a planted near-duplicate
+    (<= 20 flipped bits) at a known global row: top-1 must be exactly that row at exactly that distance."""
+    import torch
+    from vi_slam_amd import capi, dist as vdist, synth
+    b, e = vdist.shard_range(MAP_ROWS, rk.rank, rk.world)
+    # queries: ORB descriptors of the first frame of the base scene (the same on every rank), padded to 2000 if short
+    img = capi.alloc_image(1, H, W, rk.dev)
+    img.copy_(torch.from_numpy(synth.scene(synth.BASE_SEED, W, H, 0)[None]).to(rk.dev))
+    orb = capi.Orb(1, H, W, ORB_NFEAT, ORB_SCALE, ORB_LEVELS, ORB_FAST_THR, device=rk.dev)
+    orb(img)
+    _, desc = orb.host_keypoints(0)
+    q = np.concatenate([desc[:N_QUERIES], synth.descriptors(synth.MAP_SEED + 1, max(0, N_QUERIES - len(desc)))])[:N_QUERIES]
+    q = np.ascontiguousarray(q)
+    del orb, img
+    shard = synth.descriptors(synth.MAP_SEED, e - b, first=b)
+    for i in range(N_QUERIES):
+        p = planted_position(i)
+        if b <= p < e:
+            shard[p - b] = synth.flip_bits(i, q[i], i % 21)
+    qd, td = torch.from_numpy(q).to(rk.dev), torch.from_numpy(shard).to(rk.dev)
+    del shard
+    res = {}
+
+    def step():
+        res["r"] = vdist.sharded_match_knn2(qd, td, b)
+
+    elapsed, prof = timed(rk, step, steps, warmup)
+    idx, dist_ = res["r"]
+    ok, exact_top1 = verify_planted(q, idx.cpu().numpy(), dist_.cpu().numpy())
+    if not ok:
+        raise SystemExit("bench.py: relocalisation leg returned wrong neighbours for the planted duplicates")
+    rows = e - b
+    per_step = {"k_match": 32 * (N_QUERIES + rows) + 16 * N_QUERIES}
+    kernels = kernel_table(prof, elapsed, per_step, steps)
+    pairs = N_QUERIES * MAP_ROWS * steps
+    roof = roofline_for(kernels, counters, "reloc", rows)
+    out = {"workload": f"configs[4]: {N_QUERIES} query descriptors against a {MAP_ROWS}-row 256-bit map, rows sharded over "
+                       f"{rk.world} GPU(s), per-shard top-2 all-gathered (32 000 B per rank) and merged",
+           "value": N_QUERIES * steps / elapsed, "unit": "queries/s", "ms_per_query_set": elapsed / steps * 1e3, "steps": steps,
+           "pairs_per_s": pairs / elapsed, "rows_per_gpu": rows, "planted_neighbours_verified": ok, "queries_whose_top1_is_their_own_planted_row": exact_top1,
+           "collective": "all_gather (RCCL)" if rk.world > 1 and not rk.gloo else ("all_gather (gloo rehearsal)" if rk.world > 1 else "none (one shard)"),
+           "roofline": roof, "kernels": kernels}
+    if "k_match" in kernels:
+        # xor + accumulating popcount per 32-bit word, median + minimum on packed keys: 19 VALU instructions per 64 pairs
+        km = kernels["k_match"]
+        rate = N_QUERIES * rows / (km["avg_ms"] * 1e-3)
+        out["k_match_pairs_per_s"] = rate
+    return out
+
+
+def run_single_stream_leg(frames_host):
+    """configs[0] / [1] through the host-pointer API the adapters call (vfe_process_frame: upload + pyramid + KLT + refill,
+    one synchronisation per call), one live stream on this rank's GPU."""
+    from vi_slam_amd import capi, synth
+    out = {}
+    for name, (w, h, n, d, lv, nfr) in {"vga_150": (752, 480, 150, 30.0, 3, 200), "1080p_1000": (W, H, NFEAT, MIN_DIST, LEVELS, 120)}.items():
+        seq = [synth.scene(synth.BASE_SEED, w, h, t) for t in range(8)] if (w, h) != (W, H) else frames_host
+        ctx = capi.Context(w, h, max_features=n, pyramid_levels=lv, win_size=WIN, orb_levels=0)
+        order = list(range(len(seq))) + list(range(len(seq) - 2, 0, -1))
+        lat = []
+        for i in range(nfr):
+            f = seq[order[i % len(order)]]
+            t0 = time.perf_counter()
+            ctx.process_frame(f, 10**9 + i * 33_333_333, n, QUALITY, d)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        ctx.close()
+        lat = np.array(lat[10:])
+        out[name] = {"frame": f"{w}x{h}", "features": n, "levels": lv, "frames": len(lat), "median_ms": float(np.median(lat)),
+                     "p95_ms": float(np.percentile(lat, 95)), "frames_per_s": float(1e3 / np.median(lat)),
+                     "includes": "host-to-device upload of the frame, one synchronisation per call"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="independent streams per GPU")
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic sequences tiled over the batch")
+    ap.add_argument("--steps", type=int, default=500, help="timed steps of the headline leg (default: about one second)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="independent streams per GPU (headline leg)")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic sequences tiled over the batch")
     ap.add_argument("--frames", type=int, default=4, help="resident frames per stream (visited ping-pong)")
     ap.add_argument("--loss", type=float, default=0.05,
                     help="fraction of each stream's tracks dropped after every step (models feature loss, so that "
@@ -88,13 +520,20 @@ def main():
                     help="run the detector's eigenvalue pass beside pyramid + tracker on a helper stream: auto = the library's "
                          "rule (small batches only, so that per-kernel timings of the default run are not blurred by sharing "
                          "the chip), on / off = force")
+    ap.add_argument("--legs", default="main,streams64,orb_match,reloc,single_stream",
+                    help="comma-separated legs to run (main always runs)")
+    ap.add_argument("--orb-batch", type=int, default=64, help="streams per GPU in the orb_match leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--rehearse-one-device", action="store_true",
-                    help="multi-rank rehearsal on a box with one GPU: every rank uses cuda:0 and the barrier / max-reduce "
-                         "go over gloo (RCCL refuses two ranks on one device); not a measurement")
+                    help="multi-rank rehearsal on a box with one GPU: every rank uses cuda:0 and the collectives go over gloo "
+                         "(RCCL refuses two ranks on one device); not a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus) if not args.rehearse_one_device else launch_rehearsal(args.gpus))
     if args.overlap != "auto":
         os.environ["VFE_OVERLAP"] = "1" if args.overlap == "on" else "0"  # read once by the library at its first step
+    legs = set(args.legs.split(","))
 
     import torch
     import torch.distributed as dist
@@ -103,10 +542,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
     if args.rehearse_one_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -115,111 +558,86 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     capi.lib()
+    if os.environ.get("VFE_BENCH_WATCHDOG"):  # stack traces of every thread if a leg stalls (debugging aid)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VFE_BENCH_WATCHDOG"]), exit=True)
+    rk = Ranks(world, rank, dev, args.rehearse_one_device)
+    counters = load_counters()
 
     B = args.batch
-    host = make_frames(rank, B, min(args.distinct, B), args.frames)
+    n_distinct = min(args.distinct, B)
+    log(f"rendering {n_distinct} x {args.frames} synthetic 1080p frames")
+    host = make_frames(rank, B, n_distinct, args.frames)
+    log("headline leg")
     frames = []
     for t in range(args.frames):
         d = capi.alloc_image(B, H, W, dev)
         d.copy_(torch.from_numpy(host[t]).to(dev))
         frames.append(d)
-    pyr = [capi.alloc_pyramid(frames[0], LEVELS), capi.alloc_pyramid(frames[0], LEVELS)]
-    fe = capi.FrontendStep(B, H, W, NFEAT, LEVELS, WIN, quality=QUALITY, min_distance=MIN_DIST, device=dev)
 
-    # first frame of every stream: pyramid + initial detection (untimed)
-    cur = 0
-    pyr[cur][0] = frames[0]
-    capi.build_pyramid(pyr[cur])
-    gf = capi.GoodFeatures(B, H, W, NFEAT, device=dev)
-    c, _, cnt = gf(frames[0], QUALITY, MIN_DIST)
-    fe.pts.copy_(c)
-    fe.n_pts.copy_(cnt)
-    del gf
-    order = list(range(1, args.frames)) + list(range(args.frames - 2, -1, -1))
-    pos = 0
-    keep_den = 1000
-    keep_num = int(round((1.0 - min(max(args.loss, 0.0), 1.0)) * keep_den))
+    # ---- headline leg: configs[1] shape, `B` streams per GPU
+    leg, elapsed, kernels, roof, tracks = run_frontend_leg(rk, frames, B, args.loss, args.steps, args.warmup, counters, "main")
+    del leg
+    value = B * world * args.steps / elapsed
+    out = {
+        "metric": "front-end frames/s at 1920x1080, 1000 feats; % of HBM roofline",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8/int32/f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: 1920x1080 streams, 1000 Shi-Tomasi corners + 4-level KLT (win 21) + refill, "
+                               f"{B} independent streams per GPU per step, {args.loss:.0%} of the tracks dropped per step",
+                   "streams_per_gpu": B, "distinct_sequences": n_distinct, "track_loss_per_step": args.loss, "overlap": args.overlap,
+                   "frame_bytes": W * H, "algo_bytes_per_frame": BYTES_FRAME,
+                   "parallelism": f"streams sharded over {world} GPU(s), no collective"},
+        "frontend_frac_of_hbm_roofline": value / world * BYTES_FRAME / (HBM_PEAK_GBS * 1e9),
+        "roofline": roof, "kernels": kernels, "tracks": tracks,
+    }
 
-    def one_step():
-        nonlocal cur, pos
-        nxt = cur ^ 1
-        pyr[nxt][0] = frames[order[pos % len(order)]]
-        fe.step(pyr[cur], pyr[nxt])
-        if keep_num < keep_den:  # drop the newest tracks: n <- floor(n * keep)
-            torch.mul(fe.n_pts, keep_num, out=fe.n_pts)
-            torch.div(fe.n_pts, keep_den, rounding_mode="floor", out=fe.n_pts)
-        cur = nxt
-        pos += 1
-
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    capi.prof_enable(True)
-    capi.prof_read(reset=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    capi.prof_enable(False)
-    prof = capi.prof_read(reset=True)
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_device else dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-
-    n_tracked = fe.n_tracked.cpu().numpy()
-    n_pts = fe.n_pts.cpu().numpy()
-
+    # ---- configs[3]: 64 streams in total, split over the ranks (strong scaling)
+    if "streams64" in legs:
+        from vi_slam_amd import dist as vdist
+        b0, b1 = vdist.shard_range(64, rank, world)
+        nb = b1 - b0
+        if nb > 0 and nb <= B:
+            log(f"streams64 leg ({nb} streams on this GPU)")
+            steps64 = args.steps
+            _, el, ker, rf, trk = run_frontend_leg(rk, frames, nb, args.loss, steps64, args.warmup, counters, "streams64")
+            out["streams64"] = {"workload": f"configs[3]: 64 independent 1080p streams (detect + track) over {world} GPU(s), "
+                                            f"{nb} per GPU", "value": 64 * steps64 / el, "unit": "frames/s", "scaling": "strong",
+                                "streams_per_gpu": nb, "steps": steps64, "ms_per_step": el / steps64 * 1e3,
+                                "frac_of_hbm_roofline": 64 * steps64 / el / world * BYTES_FRAME / (HBM_PEAK_GBS * 1e9),
+                                "roofline": rf, "kernels": ker, "tracks": trk}
+    if "orb_match" in legs:
+        ob = min(args.orb_batch, B)
+        log("orb_match leg")
+        out["orb_match"] = run_orb_match_leg(rk, frames, ob, max(20, args.steps // 5), max(2, args.warmup // 2), counters)
+    frames_host_1080 = [host[t][0] for t in range(args.frames)]
+    del frames
+    torch.cuda.empty_cache()
+    if "reloc" in legs:
+        log("reloc leg")
+        out["reloc"] = run_reloc_leg(rk, max(10, args.steps // 10), 3, counters)
+    rk.barrier()
     if rank == 0:
-        kernels = {}
-        for name, (ms, n) in prof.items():
-            per_launch_bytes = ALGO_BYTES.get(name, 0) * B * args.steps / max(n, 1)
-            avg_ms = ms / n
-            kernels[name] = {"launches": int(n), "avg_ms": avg_ms, "share": ms / (elapsed * 1e3),
-                             "algo_GBs": per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None}
-        dom = max(kernels, key=lambda k: kernels[k]["share"])
-        roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["algo_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dom]["algo_GBs"] / HBM_PEAK_GBS, "traffic": None,
-                "algo_bytes_per_launch": ALGO_BYTES.get(dom, 0) * B}
-        # HBM bytes per launch from the committed counter passes of this same command (tools/profile_round.sh);
-        # only valid for the batch size they were taken at
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tr.get("streams_per_gpu") == B and dom in tr["kernels"]:
-                roof["traffic"] = tr["kernels"][dom]["total_bytes"]
-                roof["traffic_source"] = "profiles/traffic.json (" + tr.get("tag", "") + ")"
-            if dom in tr.get("limiter", {}):
-                roof["limiter"] = tr["limiter"][dom]
-        except (OSError, ValueError, KeyError):
-            pass
-        value = B * world * args.steps / elapsed
-        out = {
-            "metric": "front-end frames/s at 1920x1080, 1000 feats; % of HBM roofline",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/int32/f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1920x1080 streams, 1000 Shi-Tomasi corners + 4-level KLT (win 21) + refill, "
-                                   f"{B} independent streams per GPU per step, {args.loss:.0%} of the tracks dropped per step", "streams_per_gpu": B,
-                       "track_loss_per_step": args.loss, "overlap": args.overlap,
-                       "frame_bytes": W * H, "algo_bytes_per_frame": BYTES_PYR + BYTES_KLT + BYTES_DETECT,
-                       "parallelism": f"streams sharded over {world} GPU(s), no collective"},
-            "frontend_frac_of_hbm_roofline": value / world * (BYTES_PYR + BYTES_KLT + BYTES_DETECT) / (HBM_PEAK_GBS * 1e9),
-            "roofline": roof,
-            "kernels": kernels,
-            "tracks": {"mean_tracked": float(n_tracked.mean()), "mean_points": float(n_pts.mean())},
-        }
+        log("single_stream / cpu_baseline legs")
+        if "single_stream" in legs:
+            out["single_stream"] = run_single_stream_leg(frames_host_1080)
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline([host[t][0] for t in range(args.frames)], args.loss)
-            out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(host, args.loss, n_distinct)
+            out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["one_core"]["value"]
+        print(json.dumps(out), flush=True)
+    rk.barrier()
     if world > 1:
         dist.destroy_process_group()
+
+
+def launch_rehearsal(n):
+    """--rehearse-one-device with --gpus N: N ranks on cuda:0 over gloo (no device-count check)."""
+    env = dict(os.environ)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 if __name__ == "__main__":

@@ -73,8 +73,8 @@ void vfe_synth_noise(uint32_t seed, int w, int h, uint8_t* out, int step) {
  * The flow of frame t -> t+1 is known analytically. */
 void vfe_synth_scene(uint32_t seed, int w, int h, int t, double vx, double vy, double rot_deg,
                      uint8_t* out, int step) {
-    /* one-entry cache: consecutive frames of one sequence share the world (not thread-safe) */
-    static Canvas* cache = nullptr; static uint32_t c_seed; static int c_w, c_h;
+    /* one-entry cache per calling thread: consecutive frames of one sequence share the world */
+    static thread_local Canvas* cache = nullptr; static thread_local uint32_t c_seed; static thread_local int c_w, c_h;
     if (!cache || c_seed != seed || c_w != w || c_h != h) {
         delete cache; cache = new Canvas(seed, w, h); c_seed = seed; c_w = w; c_h = h;
     }

@@ -44,11 +44,13 @@ extern "C" int vfe_device_count(int* count) {
 }
 
 /* ---- kernel timing --------------------------------------------------------------------- */
-int g_vfe_prof_on = 0;
+std::atomic<int> g_vfe_prof_on{0};
 namespace {
 struct ProfRec { int id, dev; hipEvent_t a, b; };
-std::mutex g_prof_mu;
-std::vector<ProfRec> g_prof_open;            /* begin recorded, end pending (per thread use is sequential) */
+std::mutex g_prof_mu;                        /* guards the finished list, the event pool and the totals */
+/* begin recorded, end pending: scopes nest and close in order within a host thread, so the open list is per thread and
+ * threads (or devices driven by different threads) cannot close each other's records */
+thread_local std::vector<ProfRec> g_prof_open;
 std::vector<ProfRec> g_prof_done;
 std::vector<std::vector<hipEvent_t>> g_prof_pool; /* spare events per device: an event belongs to the device it was created on */
 double g_prof_ms[VFE_K_COUNT];
@@ -69,28 +71,36 @@ void prof_recycle(int dev, hipEvent_t e) {
 }
 }  // namespace
 
-void vfe_prof_begin(int id, hipStream_t st) {
-    std::lock_guard<std::mutex> g(g_prof_mu);
-    if (g_prof_done.size() >= PROF_MAX_PENDING) return;
+bool vfe_prof_begin(int id, hipStream_t st) {
     ProfRec r; r.id = id; r.dev = 0;
-    if (hipGetDevice(&r.dev) != hipSuccess) return;
-    r.a = prof_event(r.dev); r.b = prof_event(r.dev);
-    if (!r.a || !r.b || hipEventRecord(r.a, st) != hipSuccess) { prof_recycle(r.dev, r.a); prof_recycle(r.dev, r.b); return; }
+    if (hipGetDevice(&r.dev) != hipSuccess) return false;
+    {
+        std::lock_guard<std::mutex> g(g_prof_mu);
+        if (g_prof_done.size() >= PROF_MAX_PENDING) return false;
+        r.a = prof_event(r.dev); r.b = prof_event(r.dev);
+    }
+    if (!r.a || !r.b || hipEventRecord(r.a, st) != hipSuccess) {
+        std::lock_guard<std::mutex> g(g_prof_mu);
+        prof_recycle(r.dev, r.a); prof_recycle(r.dev, r.b);
+        return false;
+    }
     g_prof_open.push_back(r);
+    return true;
 }
 void vfe_prof_end(int id, hipStream_t st) {
-    std::lock_guard<std::mutex> g(g_prof_mu);
     for (size_t i = g_prof_open.size(); i-- > 0;)
         if (g_prof_open[i].id == id) {
             ProfRec r = g_prof_open[i];
             g_prof_open.erase(g_prof_open.begin() + i);
-            if (hipEventRecord(r.b, st) == hipSuccess) g_prof_done.push_back(r);
+            const bool ok = hipEventRecord(r.b, st) == hipSuccess;
+            std::lock_guard<std::mutex> g(g_prof_mu);
+            if (ok) g_prof_done.push_back(r);
             else { prof_recycle(r.dev, r.a); prof_recycle(r.dev, r.b); }
             return;
         }
 }
 
-extern "C" int vfe_prof_enable(int enable) { g_vfe_prof_on = enable ? 1 : 0; return VFE_OK; }
+extern "C" int vfe_prof_enable(int enable) { g_vfe_prof_on.store(enable ? 1 : 0); return VFE_OK; }
 
 extern "C" int vfe_prof_read(double* ms, long long* launches, int reset) {
     std::lock_guard<std::mutex> g(g_prof_mu);

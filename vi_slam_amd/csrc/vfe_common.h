@@ -38,12 +38,15 @@ void vfe_set_error(const char* fmt, ...);
 
 /* kernel timing: when enabled (vfe_prof_enable), every launch site brackets its kernel with
  * a pair of HIP events on the launch stream */
-extern int g_vfe_prof_on;
-void vfe_prof_begin(int id, hipStream_t st);
+#include <atomic>
+extern std::atomic<int> g_vfe_prof_on;
+bool vfe_prof_begin(int id, hipStream_t st); /* true when a record was opened (the matching end must then be called) */
 void vfe_prof_end(int id, hipStream_t st);
 struct ProfScope {
     int id; hipStream_t st; bool on;
-    ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on(g_vfe_prof_on != 0) { if (on) vfe_prof_begin(id, st); }
+    ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on(false) {
+        if (g_vfe_prof_on.load(std::memory_order_relaxed) != 0) on = vfe_prof_begin(id, st);
+    }
     ~ProfScope() { if (on) vfe_prof_end(id, st); }
 };
 

@@ -183,6 +183,14 @@ static AuxStream* aux_stream() {
     return &pool[dev];
 }
 /* side-by-side execution pays when the batch is too small to fill the chip; VFE_OVERLAP=0/1 forces it off/on */
+/* Once the helper stream has been forked, every way out of the step -- error returns included -- must leave the caller's
+ * stream waiting for it: the caller may free or reuse the workspace and the frame as soon as it has its status code. */
+struct ForkGuard {
+    AuxStream* a; hipStream_t st; bool joined;
+    ~ForkGuard() {
+        if (a && !joined && hipEventRecord(a->join, a->s) == hipSuccess) (void)hipStreamWaitEvent(st, a->join, 0);
+    }
+};
 static bool fe_overlap(int batch, int w, int h) {
     static const int forced = [] { const char* e = getenv("VFE_OVERLAP"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return forced != 0;
@@ -224,9 +232,11 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
      * helper stream forked from the caller's stream here and joined before the selection. */
     hipStream_t st = (hipStream_t)stream;
     AuxStream* aux = fe_overlap(batch, w, h) ? aux_stream() : nullptr;
+    ForkGuard guard{nullptr, st, false};
     if (aux) {
         VFE_HIP(hipEventRecord(aux->fork, st));
         VFE_HIP(hipStreamWaitEvent(aux->s, aux->fork, 0));
+        guard.a = aux;
         if ((rc = gf_eig_phase(&next_levels[0], cap, quality, min_distance, cap, ws + L.gf_off, L.gf_bytes, aux->s))) return rc;
         VFE_HIP(hipEventRecord(aux->join, aux->s));
     }
@@ -243,6 +253,7 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
     if (n_tracked) VFE_HIP(hipMemcpyAsync(n_tracked, n_pts, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (aux) {
         VFE_HIP(hipStreamWaitEvent(st, aux->join, 0));
+        guard.joined = true;
     } else if ((rc = gf_eig_phase(&next_levels[0], cap, quality, min_distance, cap, ws + L.gf_off, L.gf_bytes, st))) return rc;
     if ((rc = gf_select_phase(&next_levels[0], cap, quality, min_distance, pts, n_pts, cap, corners, nullptr, counts,
                               ws + L.gf_off, L.gf_bytes, st))) return rc;

@@ -229,6 +229,7 @@ int klt_order_launch(const float* pts, const int* n_pts, int cap, int batch, int
     int shift = 6; /* 64-pixel tiles, coarser for very large frames */
     while ((long long)((w >> shift) + 1) * ((h >> shift) + 1) > ORD_CELLS) shift++;
     const int gx = (w >> shift) + 1, cells = gx * ((h >> shift) + 1);
+    ProfScope prof(VFE_K_MISC, stream);
     hipLaunchKernelGGL(k_klt_order, dim3(batch), dim3(256), 0, stream, pts, n_pts, cap, w, h, shift, gx, cells, order);
     VFE_LAUNCH_CHECK();
     return VFE_OK;

@@ -37,8 +37,15 @@ def sharded_match_knn2(query, train_shard, base_index, group=None, match_fn=None
     if world == 1:
         return idx, d
     packed = torch.stack([idx, d]).contiguous()           # [2, nq, 2] int32: one message per rank
-    gathered = [torch.empty_like(packed) for _ in range(world)]
-    dist.all_gather(gathered, packed, group=group)
-    all_idx = torch.stack([g[0] for g in gathered])       # [world, nq, 2]
-    all_dist = torch.stack([g[1] for g in gathered])
-    return merge_fn(all_idx, all_dist)
+    device = packed.device
+    if dist.get_backend(group) == "gloo":
+        # CPU tests and one-GPU rehearsals: gloo gathers host tensors, one list entry per rank
+        host = packed.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        gathered = torch.stack(parts).to(device)
+    else:
+        # RCCL: one collective into one [world, 2, nq, 2] buffer on the GPU
+        gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=device)
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+    return merge_fn(gathered[:, 0].contiguous(), gathered[:, 1].contiguous())   # [world, nq, 2] each

@@ -18,7 +18,10 @@ void GpuFrontEnd::setEqualize(bool on) { setEqualizeMode(on ? VFE_EQ_HIST : VFE_
 
 void GpuFrontEnd::setEqualizeMode(int mode) {
     equalize_ = (mode == VFE_EQ_HIST || mode == VFE_EQ_CLAHE) ? mode : VFE_EQ_NONE;
-    if (ctx_) (void)vfe_set_equalize(ctx_, equalize_);
+    if (ctx_) {
+        const int rc = vfe_set_equalize(ctx_, equalize_);
+        if (rc != VFE_OK) { release(); (void)fail(rc); } /* the next frame rebuilds the context and reports again */
+    }
 }
 
 void GpuFrontEnd::setFRejection(double threshold, const double* camera4, const double* dist5, double virtualFocal) {
@@ -29,7 +32,10 @@ void GpuFrontEnd::setFRejection(double threshold, const double* camera4, const d
         for (int i = 0; i < 5; i++) fDist_[i] = dist5[i];
         fFocal_ = virtualFocal;
     }
-    if (ctx_) (void)vfe_set_f_rejection(ctx_, fThr_, fHaveCam_ ? fCam_ : nullptr, fHaveCam_ ? fDist_ : nullptr, fFocal_);
+    if (ctx_) {
+        const int rc = vfe_set_f_rejection(ctx_, fThr_, fHaveCam_ ? fCam_ : nullptr, fHaveCam_ ? fDist_ : nullptr, fFocal_);
+        if (rc != VFE_OK) { release(); (void)fail(rc); }
+    }
 }
 
 void GpuFrontEnd::release() {
@@ -49,10 +55,13 @@ bool GpuFrontEnd::ensure(const ImageView& img) {
     cfg_.max_height = img.rows > cfg_.max_height ? img.rows : cfg_.max_height;
     const int rc = vfe_create(&cfg_, &ctx_);
     if (rc != VFE_OK) { ctx_ = nullptr; return fail(rc); }
-    (void)vfe_set_equalize(ctx_, equalize_);
+    /* a context that could not take its configuration must not survive: the next frame would find it alive and run
+     * with the option silently off */
+    const int rcE = vfe_set_equalize(ctx_, equalize_);
+    if (rcE != VFE_OK) { release(); return fail(rcE); }
     if (fThr_ > 0) {
         const int rcF = vfe_set_f_rejection(ctx_, fThr_, fHaveCam_ ? fCam_ : nullptr, fHaveCam_ ? fDist_ : nullptr, fFocal_);
-        if (rcF != VFE_OK) return fail(rcF);
+        if (rcF != VFE_OK) { release(); return fail(rcF); }
     }
     error_.clear();
     return true;
