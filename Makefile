@@ -4,10 +4,12 @@
 #   oracle/libvfe_oracle.so          CPU oracle (test infrastructure only)
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
-LIBDIR = vi_slam_amd/lib
+LIBDIR ?= vi_slam_amd/lib
 CSRC = vi_slam_amd/csrc
 # -ffp-contract=off: every float operation rounds once, exactly as in the CPU oracle.
-HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$(CSRC) -Wall
+# EXTRA: experiment switches (-D...), used with LIBDIR=/OBJDIR= overrides to build a variant library beside the default one
+EXTRA ?=
+HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$(CSRC) -Wall $(EXTRA)
 
 HIP_SRCS = $(wildcard $(CSRC)/*.hip)
 HIP_HDRS = $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/vfe.h
@@ -28,7 +30,7 @@ $(LIBDIR)/libvfe_synth.so: $(CSRC)/synth.cpp | $(LIBDIR)
 	$(CXX) -O2 -std=c++17 -fPIC -shared -o $@ $<
 
 # one object per source so that `make -j` compiles them side by side (no device code is shared across files)
-OBJDIR = build/obj
+OBJDIR ?= build/obj
 HIP_OBJS = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRCS))
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	@mkdir -p $(OBJDIR)

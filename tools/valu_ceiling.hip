@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -43,14 +44,19 @@ enum Cls {
     C_ADD_F32, C_FMA_F32, C_MAX3_F32, C_ADD_U32, C_XOR, C_AND_OR, C_LSHL, C_MIN_U32, C_MED3_U32, C_BCNT, C_CNDMASK,
     C_MAD_U24, C_MUL_LO, C_PERM, C_PK_ADD_I16, C_PK_MAX_I16, C_PK_MUL_LO_U16, C_PK_MAD_I16, C_DOT2_I32_I16, C_DOT4_U32_U8,
     C_PK_FMA_F32, C_PK_MUL_F32, C_PK_ADD_F32, C_MOV_DPP_ROW, C_MOV_DPP_WAVE, C_ADD_DPP_ROW, C_RSQ, C_SQRT, C_RCP, C_CVT_F32_I32,
-    C_MOV, C_COUNT
+    C_MOV, C_MUL_F32, C_SUB_F32, C_MAX_F32, C_MIN_F32, C_AND, C_OR, C_LSHL_V, C_LSHR, C_ASHR, C_BFE, C_CVT_UB0, C_CVT_UB3,
+    C_CNDMASK_S, C_SUB_U32, C_ADD3, C_LSHL_ADD, C_LSHL_OR, C_MUL_U24, C_ALIGNBIT, C_PK_SUB_I16, C_PK_LSHR_B16, C_SAD_U8, C_FMAC_F32,
+    C_MAD_I24, C_MAX_U32, C_CVT_U32_F32, C_RNDNE, C_CVT_I32_F32, C_MAX_I32, C_ADD_I16, C_MAD_U16, C_COUNT
 };
 static const char* kNames[C_COUNT] = {
     "v_add_f32", "v_fma_f32", "v_max3_f32", "v_add_u32", "v_xor_b32", "v_and_or_b32", "v_lshlrev_b32", "v_min_u32", "v_med3_u32",
     "v_bcnt_u32_b32", "v_cndmask_b32", "v_mad_u32_u24", "v_mul_lo_u32", "v_perm_b32", "v_pk_add_i16", "v_pk_max_i16",
     "v_pk_mul_lo_u16", "v_pk_mad_i16", "v_dot2_i32_i16", "v_dot4_u32_u8", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32",
     "v_mov_b32 dpp row_shr:1", "v_mov_b32 dpp wave_shr:1", "v_add_u32 dpp row_shr:1", "v_rsq_f32", "v_sqrt_f32", "v_rcp_f32",
-    "v_cvt_f32_i32", "v_mov_b32"};
+    "v_cvt_f32_i32", "v_mov_b32", "v_mul_f32", "v_sub_f32", "v_max_f32", "v_min_f32", "v_and_b32", "v_or_b32", "v_lshlrev_b32 (vgpr shift)",
+    "v_lshrrev_b32", "v_ashrrev_i32", "v_bfe_u32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte3", "v_cndmask_b32 (sgpr mask)", "v_sub_u32",
+    "v_add3_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_mul_u32_u24", "v_alignbit_b32", "v_pk_sub_i16", "v_pk_lshrrev_b16", "v_sad_u8",
+    "v_fmac_f32", "v_mad_i32_i24", "v_max_u32", "v_cvt_u32_f32", "v_rndne_f32", "v_cvt_i32_f32", "v_max_i32", "v_add_u16", "v_mad_u16"};
 
 template <int CLS>
 __global__ __launch_bounds__(1024) void k_issue(long long* __restrict__ stamps, uint32_t* __restrict__ sink, int trips, uint32_t seed) {
@@ -63,6 +69,7 @@ __global__ __launch_bounds__(1024) void k_issue(long long* __restrict__ stamps, 
     }
     uint32_t c0 = seed | 0x00010001u, c1 = (seed >> 3) | 0x01000100u;
     unsigned long long d0 = ((unsigned long long)__float_as_uint(0.999999f) << 32) | __float_as_uint(1.000001f), d1 = d0;
+    const unsigned long long smask = __builtin_amdgcn_ballot_w64((threadIdx.x & 1) == (seed & 1)); /* a wave-uniform SGPR-pair mask */
     __syncthreads();
     const long long t0 = clock64();
     for (int t = 0; t < trips; t++) {
@@ -97,6 +104,41 @@ __global__ __launch_bounds__(1024) void k_issue(long long* __restrict__ stamps, 
         else if (CLS == C_RCP) { OP32("v_rcp_f32 %0, %0") }
         else if (CLS == C_CVT_F32_I32) { OP32("v_cvt_f32_i32 %0, %0") }
         else if (CLS == C_MOV) { OP32("v_mov_b32 %0, %1") }
+        else if (CLS == C_MUL_F32) { OP32("v_mul_f32 %0, %0, %1") }
+        else if (CLS == C_SUB_F32) { OP32("v_sub_f32 %0, %0, %1") }
+        else if (CLS == C_MAX_F32) { OP32("v_max_f32 %0, %0, %1") }
+        else if (CLS == C_MIN_F32) { OP32("v_min_f32 %0, %0, %1") }
+        else if (CLS == C_AND) { OP32("v_and_b32 %0, %0, %1") }
+        else if (CLS == C_OR) { OP32("v_or_b32 %0, %0, %1") }
+        else if (CLS == C_LSHL_V) { OP32("v_lshlrev_b32 %0, %1, %0") }
+        else if (CLS == C_LSHR) { OP32("v_lshrrev_b32 %0, 3, %0") }
+        else if (CLS == C_ASHR) { OP32("v_ashrrev_i32 %0, 3, %0") }
+        else if (CLS == C_BFE) { OP32("v_bfe_u32 %0, %0, 8, 8") }
+        else if (CLS == C_CVT_UB0) { OP32("v_cvt_f32_ubyte0 %0, %0") }
+        else if (CLS == C_CVT_UB3) { OP32("v_cvt_f32_ubyte3 %0, %0") }
+        else if (CLS == C_CNDMASK_S) {
+            _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {
+                _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c0), "s"(smask));
+            }
+        }
+        else if (CLS == C_SUB_U32) { OP32("v_sub_u32 %0, %0, %1") }
+        else if (CLS == C_ADD3) { OP32("v_add3_u32 %0, %0, %1, %2") }
+        else if (CLS == C_LSHL_ADD) { OP32("v_lshl_add_u32 %0, %0, 2, %1") }
+        else if (CLS == C_LSHL_OR) { OP32("v_lshl_or_b32 %0, %0, 2, %1") }
+        else if (CLS == C_MUL_U24) { OP32("v_mul_u32_u24 %0, %0, %1") }
+        else if (CLS == C_ALIGNBIT) { OP32("v_alignbit_b32 %0, %0, %1, 16") }
+        else if (CLS == C_PK_SUB_I16) { OP32("v_pk_sub_i16 %0, %0, %1") }
+        else if (CLS == C_PK_LSHR_B16) { OP32("v_pk_lshrrev_b16 %0, 1, %0 op_sel_hi:[0,1]") }
+        else if (CLS == C_SAD_U8) { OP32("v_sad_u8 %0, %0, %1, %2") }
+        else if (CLS == C_FMAC_F32) { OP32("v_fmac_f32 %0, %1, %2") }
+        else if (CLS == C_MAD_I24) { OP32("v_mad_i32_i24 %0, %0, %1, %2") }
+        else if (CLS == C_MAX_U32) { OP32("v_max_u32 %0, %0, %1") }
+        else if (CLS == C_CVT_U32_F32) { OP32("v_cvt_u32_f32 %0, %0") }
+        else if (CLS == C_RNDNE) { OP32("v_rndne_f32 %0, %0") }
+        else if (CLS == C_CVT_I32_F32) { OP32("v_cvt_i32_f32 %0, %0") }
+        else if (CLS == C_MAX_I32) { OP32("v_max_i32 %0, %0, %1") }
+        else if (CLS == C_ADD_I16) { OP32("v_add_u16 %0, %0, %1") }
+        else if (CLS == C_MAD_U16) { OP32("v_mad_u16 %0, %0, %1, %2") }
     }
     const long long t1 = clock64();
     uint32_t acc = 0;
@@ -118,6 +160,8 @@ template <> struct Fill<C_COUNT> { static void go(kern_t*) {} };
 
 int main(int argc, char** argv) {
     const bool csv = argc > 1 && !strcmp(argv[1], "--csv");
+    int first_cls = 0; /* --from N: start at class N (the classes of an earlier table need not be measured again) */
+    for (int i = 1; i + 1 < argc; i++) if (!strcmp(argv[i], "--from")) first_cls = atoi(argv[i + 1]);
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -138,7 +182,7 @@ int main(int argc, char** argv) {
            prop.clockRate, trips * PER_TRIP);
     printf(csv ? "class,waves_per_simd,cycles_per_inst_one_cu,inst_per_cycle_per_simd_one_cu,chip_ns_per_inst_per_simd,chip_inst_per_ns_per_simd\n"
                : "%-28s %5s %12s %12s %14s\n", "class", "w/SIMD", "cyc/inst(CU)", "inst/cyc/SIMD", "chip ns/inst/SIMD");
-    for (int c = 0; c < C_COUNT; c++) {
+    for (int c = first_cls; c < C_COUNT; c++) {
         for (int wps : wps_list) {
             /* 6 and 8 waves per SIMD come from two co-resident workgroups on the CU: measure them on the full chip only for
              * the wall-clock figure, and on one CU with a single workgroup of up to 1024 threads (4 waves per SIMD) */

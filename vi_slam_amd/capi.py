@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvfe.so")
+# VFE_LIB_PATH: a variant build of the same library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("VFE_LIB_PATH") or os.path.join(_HERE, "lib", "libvfe.so")
 _LIB = None
 
 VFE_MAX_LEVELS = 16

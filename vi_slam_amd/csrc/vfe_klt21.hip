@@ -230,7 +230,10 @@ __device__ static inline int piece_residual(const unsigned* areaJ, const unsigne
 }
 
 /* three waves per SIMD: 168 registers, which the kernel fits but for a handful of spills */
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_klt21(KltParams p) {
+#ifndef KLT21_WPE
+#define KLT21_WPE 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, KLT21_WPE))) void k_klt21(KltParams p) {
     __shared__ __align__(16) unsigned s_patch[4][PATCH_DW];
     __shared__ __align__(16) unsigned s_patch2[4][PATCH_DW]; /* template patch for the residual pass */
     const int lane = threadIdx.x, sub = lane & 15, q = lane >> 4;
