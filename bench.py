@@ -334,17 +334,31 @@ class FrontendLeg:
         return e0.elapsed_time(e1) / reps
 
 
-def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg):
+def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg, overlap):
+    """-> (seconds of the timed region, kernel table, roofline, track statistics, timing note).  With the detector running
+    beside the tracker (the library's default) per-kernel durations inside the timed region are those of kernels sharing the
+    chip, so the kernel table and the roofline come from a second, shorter pass with everything on one stream."""
+    from vi_slam_amd import capi
     L = FrontendLeg(frames, batch, loss, rk.dev)
+    capi.set_overlap(overlap)
     elapsed, prof = timed(rk, L.step, steps, warmup)
-    kernels = kernel_table(prof, elapsed, {k: v * batch for k, v in ALGO_BYTES.items()}, steps)
+    k_elapsed, k_steps = elapsed, steps
+    note = "kernel durations from the timed region itself (one stream)"
+    if overlap:
+        capi.set_overlap(False)
+        k_steps = max(10, min(steps, 100))
+        k_elapsed, prof = timed(rk, L.step, k_steps, 2)
+        capi.set_overlap(True)
+        note = (f"kernel durations from a separate pass of {k_steps} steps with every kernel on one stream "
+                f"({k_elapsed / k_steps * 1e3:.3f} ms per step); in the timed region the eigenvalue pass runs beside pyramid + tracker")
+    kernels = kernel_table(prof, k_elapsed, {k: v * batch for k, v in ALGO_BYTES.items()}, k_steps)
     extra_ms = L.torch_kernels_ms() if L.keep_num < L.keep_den else 0.0
-    kernels["torch_track_loss"] = {"launches": 2 * steps, "avg_ms": extra_ms / 2, "share": extra_ms * steps / (elapsed * 1e3),
+    kernels["torch_track_loss"] = {"launches": 2 * k_steps, "avg_ms": extra_ms / 2, "share": extra_ms * k_steps / (k_elapsed * 1e3),
                                    "algo_bytes_per_launch": 8 * batch, "algo_GBs": None,
                                    "what": "n_pts <- floor(n_pts * keep): two element-wise torch kernels per step, timed apart"}
     tracked = float(L.fe.n_tracked.float().mean().item())
     points = float(L.fe.n_pts.float().mean().item())
-    return L, elapsed, kernels, roofline_for(kernels, counters, leg, batch), {"mean_tracked": tracked, "mean_points": points}
+    return elapsed, kernels, roofline_for(kernels, counters, leg, batch), {"mean_tracked": tracked, "mean_points": points}, note
 
 
 def orb_level_pixels():
@@ -516,10 +530,9 @@ def main():
     ap.add_argument("--loss", type=float, default=0.05,
                     help="fraction of each stream's tracks dropped after every step (models feature loss, so that "
                          "every frame has corners to refill; the synthetic scene alone loses almost none)")
-    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
-                    help="run the detector's eigenvalue pass beside pyramid + tracker on a helper stream: auto = the library's "
-                         "rule (small batches only, so that per-kernel timings of the default run are not blurred by sharing "
-                         "the chip), on / off = force")
+    ap.add_argument("--overlap", choices=["on", "off"], default="on",
+                    help="on (the library's default): the detector's eigenvalue pass runs beside pyramid + tracker on a helper "
+                         "stream, and per-kernel durations come from a separate one-stream pass; off: everything on one stream")
     ap.add_argument("--legs", default="main,streams64,orb_match,reloc,single_stream",
                     help="comma-separated legs to run (main always runs)")
     ap.add_argument("--orb-batch", type=int, default=64, help="streams per GPU in the orb_match leg")
@@ -531,8 +544,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus) if not args.rehearse_one_device else launch_rehearsal(args.gpus))
-    if args.overlap != "auto":
-        os.environ["VFE_OVERLAP"] = "1" if args.overlap == "on" else "0"  # read once by the library at its first step
+    overlap = args.overlap == "on"
     legs = set(args.legs.split(","))
 
     import torch
@@ -576,8 +588,7 @@ def main():
         frames.append(d)
 
     # ---- headline leg: configs[1] shape, `B` streams per GPU
-    leg, elapsed, kernels, roof, tracks = run_frontend_leg(rk, frames, B, args.loss, args.steps, args.warmup, counters, "main")
-    del leg
+    elapsed, kernels, roof, tracks, knote = run_frontend_leg(rk, frames, B, args.loss, args.steps, args.warmup, counters, "main", overlap)
     value = B * world * args.steps / elapsed
     out = {
         "metric": "front-end frames/s at 1920x1080, 1000 feats; % of HBM roofline",
@@ -590,7 +601,7 @@ def main():
                    "frame_bytes": W * H, "algo_bytes_per_frame": BYTES_FRAME,
                    "parallelism": f"streams sharded over {world} GPU(s), no collective"},
         "frontend_frac_of_hbm_roofline": value / world * BYTES_FRAME / (HBM_PEAK_GBS * 1e9),
-        "roofline": roof, "kernels": kernels, "tracks": tracks,
+        "roofline": roof, "kernels": kernels, "kernel_timing": knote, "tracks": tracks,
     }
 
     # ---- configs[3]: 64 streams in total, split over the ranks (strong scaling)
@@ -601,12 +612,12 @@ def main():
         if nb > 0 and nb <= B:
             log(f"streams64 leg ({nb} streams on this GPU)")
             steps64 = args.steps
-            _, el, ker, rf, trk = run_frontend_leg(rk, frames, nb, args.loss, steps64, args.warmup, counters, "streams64")
+            el, ker, rf, trk, kn = run_frontend_leg(rk, frames, nb, args.loss, steps64, args.warmup, counters, "streams64", overlap)
             out["streams64"] = {"workload": f"configs[3]: 64 independent 1080p streams (detect + track) over {world} GPU(s), "
                                             f"{nb} per GPU", "value": 64 * steps64 / el, "unit": "frames/s", "scaling": "strong",
                                 "streams_per_gpu": nb, "steps": steps64, "ms_per_step": el / steps64 * 1e3,
                                 "frac_of_hbm_roofline": 64 * steps64 / el / world * BYTES_FRAME / (HBM_PEAK_GBS * 1e9),
-                                "roofline": rf, "kernels": ker, "tracks": trk}
+                                "roofline": rf, "kernels": ker, "kernel_timing": kn, "tracks": trk}
     if "orb_match" in legs:
         ob = min(args.orb_batch, B)
         log("orb_match leg")

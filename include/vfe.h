@@ -225,6 +225,13 @@ int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg* next_leve
                           int win, int max_iter, double eps, double min_eig_thr,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* vfe_dev_frontend_step runs the detector's eigenvalue pass on a helper stream of the library (one per host thread and
+ * device, forked from and joined back into the caller's stream) beside pyramid + tracker: mode 1 (default).  mode 0
+ * keeps every kernel on the caller's stream, in order -- what a profiler wants to see.  The environment variable
+ * VFE_OVERLAP=0/1 sets the initial mode.  Process-wide.  No counterpart in the reference, whose adapters make one
+ * blocking OpenCV call per frame (src/slam/adapters/openvins_adapter.cpp:78-80). */
+int vfe_set_overlap(int mode);
+
 /* The same step with the epipolar outlier filter of VINS-style front-ends (`F_threshold`, reference
  * config/vins_mono.yaml:101) between tracking and refill: tracks that left the image are dropped, the rest is
  * filtered by vfe_dev_fundamental_ransac on (previous, tracked) positions -- lifted to a virtual pinhole camera of

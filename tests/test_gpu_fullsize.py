@@ -122,3 +122,48 @@ def test_relocalisation_shard_properties(cuda):
     sel = np.array([0, 1, 777, 1999])
     ridx, rdist = ora.match_knn2(q[sel], t)
     assert np.array_equal(hi[sel], ridx) and np.array_equal(hd[sel], rdist)
+
+
+def test_frontend_64_streams_1080p(cuda):
+    """configs[3] at its stated shape: 64 independent 1080p streams (8 distinct sequences, each eight times) through
+    vfe_dev_frontend_step for three steps; every stream's point set equals the oracle's sequence bit for bit, and copies
+    of one sequence agree with each other.  The oracle runs once per distinct sequence."""
+    import torch
+    n, q, d, levels, B, D = 1000, 0.01, 20.0, 4, 64, 8
+    seqs = [[synth.scene(synth.BASE_SEED + 40 + s, W, H, t) for t in range(4)] for s in range(D)]
+    frames = [to_dev([seqs[b % D][t] for b in range(B)], cuda) for t in range(4)]
+    pyr = [capi.alloc_pyramid(frames[0], levels), capi.alloc_pyramid(frames[0], levels)]
+    fe = capi.FrontendStep(B, H, W, n, levels, 21, quality=q, min_distance=d, device=cuda)
+    capi.build_pyramid(pyr[0])
+    gf = capi.GoodFeatures(B, H, W, n, device=cuda)
+    c, _, cnt = gf(frames[0], q, d)
+    fe.pts.copy_(c); fe.n_pts.copy_(cnt)
+    del gf
+    ref = [ora.good_features(seqs[s][0], n, q, d)[0] for s in range(D)]
+    cur = 0
+    for t in range(1, 4):
+        nxt = cur ^ 1
+        pyr[nxt][0] = frames[t]
+        fe.step(pyr[cur], pyr[nxt])
+        cur = nxt
+        got_n = fe.n_pts.cpu().numpy()
+        got = fe.pts.cpu().numpy()
+        for s in range(D):
+            out, st, _ = ora.klt_track(seqs[s][t - 1], seqs[s][t], ref[s], 21, levels - 1)
+            r = np.rint(out)
+            keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < W - 1) & (r[:, 1] >= 1) & (r[:, 1] < H - 1)
+            tracked = out[keep]
+            new = np.zeros((0, 2), np.float32)
+            if n - len(tracked) > 0:
+                new, _ = ora.good_features(seqs[s][t], n - len(tracked), q, d, seeds=tracked)
+            ref[s] = np.concatenate([tracked, new]) if len(new) else tracked
+        for b in range(B):
+            rs = ref[b % D]
+            assert got_n[b] == len(rs), f"step {t} stream {b}"
+            assert np.array_equal(got[b, :got_n[b]].view(np.uint32), rs.view(np.uint32)), f"step {t} stream {b}"
+        # every stream drops its newest 5 % (bench.py's track-loss model), the oracle sequences likewise
+        keep_n = got_n.astype(np.int64) * 950 // 1000
+        fe.n_pts.copy_(torch.from_numpy(keep_n.astype(np.int32)).to(cuda))
+        for s in range(D):
+            ref[s] = ref[s][:int(len(ref[s]) * 950 // 1000)]
+    torch.cuda.synchronize()

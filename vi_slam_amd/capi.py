@@ -87,6 +87,7 @@ SIGNATURES = {
     "vfe_set_f_rejection": (C.c_int, [_P, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]),
     "vfe_dev_frontend_step": (C.c_int, [_DI, _DI, C.c_int, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int,
                                         C.c_int, C.c_double, C.c_double, _P, C.c_size_t, _P]),
+    "vfe_set_overlap": (C.c_int, [C.c_int]),
     "vfe_prof_enable": (C.c_int, [C.c_int]),
     "vfe_prof_read": (C.c_int, [_P, _P, C.c_int]),
     "vfe_prof_kernel_name": (C.c_char_p, [C.c_int]),
@@ -377,6 +378,11 @@ class FrontendStep:
 
 
 K_NAMES = None
+
+
+def set_overlap(on):
+    """Detector beside the tracker on a helper stream (default) or everything in order on the caller's stream."""
+    check(lib().vfe_set_overlap(1 if on else 0))
 
 
 def prof_enable(on=True):
