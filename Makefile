@@ -17,7 +17,7 @@ HIP_HDRS = $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/vfe.h
 HOST = vi_slam_amd/host
 HOST_SRCS = $(wildcard $(HOST)/src/*.cpp)
 HOST_HDRS = $(wildcard $(HOST)/include/*/*.hpp) $(wildcard $(HOST)/include/*/*/*.hpp) include/vfe.h
-CPP_TESTS = $(patsubst tests/cpp/%.cpp,tests/cpp/bin/%,$(wildcard tests/cpp/*.cpp))
+CPP_TESTS = $(patsubst tests/cpp/%.cpp,tests/cpp/bin/%,$(wildcard tests/cpp/*.cpp)) tests/cpp/bin/pc_client_video_callback
 
 HIP_TESTS = $(patsubst tests/hip/%.hip,tests/cpp/bin/%,$(wildcard tests/hip/*.hip)) tests/cpp/bin/valu_ceiling
 
@@ -45,6 +45,11 @@ $(LIBDIR)/libvi_slam_amd.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/libvfe.so
 
 # lifecycle tests in the reference's style (plain main(), exit code 1 on failure)
 tests/cpp/bin/%: tests/cpp/%.cpp $(LIBDIR)/libvi_slam_amd.so
+	@mkdir -p tests/cpp/bin
+	$(CXX) -O1 -std=c++17 -Wall -I$(HOST)/include -Iinclude -o $@ $< -L$(LIBDIR) -lvi_slam_amd -lvfe -Wl,-rpath,'$$ORIGIN/../../../$(LIBDIR)' -lpthread
+
+# the PC client's receiver callbacks written out (compiles against the host layer only)
+tests/cpp/bin/pc_client_video_callback: $(HOST)/examples/pc_client_video_callback.cpp $(LIBDIR)/libvi_slam_amd.so
 	@mkdir -p tests/cpp/bin
 	$(CXX) -O1 -std=c++17 -Wall -I$(HOST)/include -Iinclude -o $@ $< -L$(LIBDIR) -lvi_slam_amd -lvfe -Wl,-rpath,'$$ORIGIN/../../../$(LIBDIR)' -lpthread
 

@@ -97,6 +97,41 @@ def test_vins_mono_stream_tracks_and_refills(cuda, tmp_path):
     e.close()
 
 
+def test_frontend_stats_reach_the_observer(cuda, tmp_path):
+    """Egress: per-frame tracked / detected / total, latency window and per-stage GPU times through the engine's
+    statistics observer, consistent with what the adapter itself reports."""
+    import json
+    frames = [synth.scene(synth.BASE_SEED + 54, W, H, t) for t in range(6)]
+    e = make_engine(tmp_path, eng.VINS_MONO, VINS_YAML)
+    assert e.stats() is None
+    e.enable_stage_timing(True)
+    totals = []
+    for t, f in enumerate(frames):
+        e.process_image(f, 10**9 + t * 33_333_333)
+        st = e.stats()
+        assert st["ok"] and st["frames"] == t + 1 and st["failed"] == 0
+        assert st["total"] == e.tracked_count() == st["tracked"] + st["detected"]
+        if t == 0:
+            assert st["tracked"] == 0 and st["detected"] == st["total"] > 100
+        else:
+            assert 0 < st["tracked"] <= totals[-1]
+        totals.append(st["total"])
+        assert st["latency_us"] > 0
+    assert e.stats_callbacks() == len(frames)
+    st = e.stats()
+    assert 0 < st["avg_latency_us"] <= st["p99_latency_us"]
+    stages = e.stage_us()
+    assert stages.get("k_klt", 0) > 0 and stages.get("k_gftt_eig", 0) > 0 and stages.get("k_pyr_down", 0) > 0
+    assert sum(stages.values()) <= st["latency_us"] * 1.5
+    j = json.loads(e.stats_json())
+    assert j["frontend"]["frame"] == len(frames) and j["frontend"]["total"] == st["total"] and "stages_us" in j["frontend"]
+    assert abs(j["timestamp"] - (1.0 + 5 * 0.033333333)) < 1e-6
+    e.enable_stage_timing(False)
+    e.reset_latency_stats()
+    assert e.stats()["avg_latency_us"] == 0.0
+    e.close()
+
+
 def test_streaming_latency_shape_of_the_reference_e2e(cuda, tmp_path):
     """test_basic_streaming's assertion (avg per-frame latency < 100 ms) on its 640x480 noise frames."""
     frames = [synth.noise(1000 + i, 640, 480) for i in range(20)]

@@ -21,6 +21,26 @@ def test_cpp_lifecycle_programs(prog):
     assert "passed" in r.stdout
 
 
+def test_frontend_stats_program():
+    """FrontEndStats arithmetic (the reference's average / P99 window) and the engine's observer hook."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "test_frontend_stats")
+    assert os.path.exists(exe), "run `make` first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "frontend stats ok" in r.stdout
+
+
+def test_pc_client_callback_example_runs():
+    """The receiver callbacks of the reference's PC client written out: 60 fabricated frames and their IMU packets through
+    StreamIngest into the engine; every frame is accounted for, with or without a GPU."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "pc_client_video_callback")
+    assert os.path.exists(exe), "run `make` first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "and 60 frames (0 frames dropped before the engine)" in r.stdout
+    assert "front-end: 60 frames" in r.stdout and '"frontend":{"frame":60' in r.stdout
+
+
 def write(tmp_path, name, text):
     p = tmp_path / name
     p.write_text(text)

@@ -42,6 +42,12 @@ def lib():
             ("vis_engine_frontend_error", [C.c_void_p], C.c_char_p),
             ("vis_engine_points", [C.c_void_p, C.c_void_p, C.c_int], C.c_int),
             ("vis_engine_config_value", [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)], C.c_int),
+            ("vis_engine_stats_callbacks", [C.c_void_p], C.c_long),
+            ("vis_engine_enable_stage_timing", [C.c_void_p, C.c_int], None),
+            ("vis_engine_stats", [C.c_void_p, C.POINTER(C.c_double)], C.c_int),
+            ("vis_engine_stage_us", [C.c_void_p, C.POINTER(C.c_double)], C.c_int),
+            ("vis_engine_stats_json", [C.c_void_p], C.c_char_p),
+            ("vis_engine_reset_latency_stats", [C.c_void_p], None),
         ]:
             fn = getattr(L, name)
             fn.argtypes = args
@@ -123,6 +129,40 @@ class SLAMEngine:
         out = np.zeros((cap, 2), np.float32)
         n = lib().vis_engine_points(self._h, out.ctypes.data, cap)
         return out[:n].copy()
+
+    def stats(self):
+        """Front-end statistics kept by the engine: dict with frames, failed, avg_latency_us, p99_latency_us and the last
+        frame's ok / tracked / detected / total / latency_us (None before the first frame reached the front-end)."""
+        out = (C.c_double * 9)()
+        if not lib().vis_engine_stats(self._h, out):
+            return None
+        keys = ("frames", "failed", "avg_latency_us", "p99_latency_us", "ok", "tracked", "detected", "total", "latency_us")
+        d = dict(zip(keys, list(out)))
+        for k in ("frames", "failed", "tracked", "detected", "total"):
+            d[k] = int(d[k])
+        d["ok"] = bool(d["ok"])
+        return d
+
+    def stats_callbacks(self):
+        return lib().vis_engine_stats_callbacks(self._h)
+
+    def stats_json(self):
+        return lib().vis_engine_stats_json(self._h).decode()
+
+    def enable_stage_timing(self, on=True):
+        lib().vis_engine_enable_stage_timing(self._h, 1 if on else 0)
+
+    def stage_us(self):
+        """GPU microseconds per stage of the last frame, {stage name: us}; empty unless stage timing is on."""
+        from . import capi
+        out = (C.c_double * 13)()
+        if not lib().vis_engine_stage_us(self._h, out):
+            return {}
+        L = capi.lib()
+        return {L.vfe_prof_kernel_name(i).decode(): out[i] for i in range(13) if out[i] > 0}
+
+    def reset_latency_stats(self):
+        lib().vis_engine_reset_latency_stats(self._h)
 
     def config_value(self, key):
         v = C.c_double(0)

@@ -29,6 +29,7 @@ public:
     void shutdown() override;
     int getTrackedFeatureCount() const override { return trackedFeatureCount_.load(); }
     std::string getFrontEndError() const override;
+    bool getLastFrameStats(FrontEndFrameStats& out) const override;
     bool isReadyForVision() const;
 
 protected:
@@ -58,6 +59,10 @@ protected:
     /* called when estimatePose fails; default: TRACKING -> LOST */
     virtual bool lostWhenNoPose() const { return true; }
 
+    /* feedImage reports how the frame's features split up (tracked from the previous frame / new); detectors that
+     * start from scratch every frame report everything as detected */
+    void reportFrame(int tracked, int detected, int total) { frameTracked_ = tracked; frameDetected_ = detected; frameTotal_ = total; }
+
     GpuFrontEnd frontEnd_;
     Traits traits_;
 
@@ -74,6 +79,10 @@ private:
     std::atomic<bool> initialized_{false}, calibrated_{false};
     std::atomic<int> trackedFeatureCount_{0};
     bool imuInitialized_ = false;
+    int frameTracked_ = 0, frameDetected_ = 0, frameTotal_ = 0; /* set by feedImage through reportFrame */
+    mutable std::mutex frameStatsMutex_;
+    FrontEndFrameStats lastFrame_;
+    uint64_t frameIndex_ = 0;
 };
 
 /* helpers for the line-oriented `key: value` files the reference parses by hand */

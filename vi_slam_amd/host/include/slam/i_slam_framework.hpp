@@ -5,6 +5,7 @@
  * (ImageView instead of cv::Mat, see image_view.hpp). */
 #include "common/types.hpp"
 #include "slam/image_view.hpp"
+#include "slam/output/frontend_stats.hpp"
 #include <string>
 #include <vector>
 
@@ -27,6 +28,8 @@ public:
     virtual int getTrackedFeatureCount() const = 0;
     /* last front-end (GPU) error message, empty if none: process calls never throw */
     virtual std::string getFrontEndError() const = 0;
+    /* what the front-end did with the last frame that reached it (false before the first one) */
+    virtual bool getLastFrameStats(FrontEndFrameStats& out) const = 0;
 };
 
 }  // namespace vi_slam

@@ -39,6 +39,16 @@ public:
     /* additions of this build */
     int getTrackedFeatureCount() const;
     std::string getFrontEndError() const;
+    /* Front-end statistics for observers (the egress the reference has only for poses, zmq_publisher.hpp:85-118):
+     * the callback fires after every processImage that reached an adapter, on the caller's thread with the engine's
+     * mutexes held -- like the pose and status callbacks it must not call back into the engine; frontEndStats() keeps
+     * the running window (average / P99 latency, counts) and can be read from any thread. */
+    void setFrontEndStatsCallback(FrontEndStatsCallback callback);
+    const FrontEndStats& frontEndStats() const { return stats_; }
+    FrontEndStats& frontEndStats() { return stats_; }
+    /* per-stage GPU times in every FrontEndFrameStats (HIP events around each kernel; process-wide switch of the GPU
+     * library, so use it with one engine per process) */
+    void enableStageTiming(bool on);
     ISLAMFramework* framework() { return framework_.get(); }
 
 private:
@@ -49,6 +59,9 @@ private:
     SLAMFrameworkType currentType_;
     PoseCallback poseCallback_;
     StatusCallback statusCallback_;
+    FrontEndStatsCallback statsCallback_;
+    FrontEndStats stats_;
+    bool stageTiming_ = false;
     mutable std::mutex frameworkMutex_, callbackMutex_;
     bool initialized_;
 };

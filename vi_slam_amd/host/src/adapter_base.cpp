@@ -1,4 +1,5 @@
 #include "slam/adapters/adapter_base.hpp"
+#include <chrono>
 #include "common/logging.hpp"
 #include <cmath>
 #include <fstream>
@@ -106,7 +107,10 @@ void AdapterBase::processImage(const ImageView& image, int64_t timestampNs) {
             imuBuffer_.pop_front();
         }
     }
+    frameTracked_ = frameDetected_ = frameTotal_ = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     const int tracked = feedImage(image, timestampNs, since);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     lastImageTimestampNs_ = timestampNs;
     if (tracked >= 0) trackedFeatureCount_ = tracked;
 
@@ -118,6 +122,24 @@ void AdapterBase::processImage(const ImageView& image, int64_t timestampNs) {
         status_ = TrackingStatus::LOST;
         LOG_WARN(traits_.name, "Tracking lost");
     }
+    {
+        std::lock_guard<std::mutex> lock(frameStatsMutex_);
+        lastFrame_ = FrontEndFrameStats();
+        lastFrame_.timestampNs = timestampNs;
+        lastFrame_.frameIndex = ++frameIndex_;
+        lastFrame_.ok = tracked >= 0;
+        lastFrame_.tracked = frameTracked_; lastFrame_.detected = frameDetected_;
+        lastFrame_.total = tracked >= 0 ? (frameTotal_ ? frameTotal_ : tracked) : 0;
+        lastFrame_.latencyUs = us;
+        lastFrame_.status = status_.load();
+    }
+}
+
+bool AdapterBase::getLastFrameStats(FrontEndFrameStats& out) const {
+    std::lock_guard<std::mutex> lock(frameStatsMutex_);
+    if (frameIndex_ == 0) return false;
+    out = lastFrame_;
+    return true;
 }
 
 void AdapterBase::processIMU(const IMUSample& imu) {

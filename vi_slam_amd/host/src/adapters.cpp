@@ -41,6 +41,7 @@ void VINSMonoAdapter::configDone() {
 int VINSMonoAdapter::feedImage(const ImageView& image, int64_t timestampNs, const std::vector<IMUSample>&) {
     vfe_frame_stats st{0, 0, 0};
     if (!frontEnd_.processFrame(image, timestampNs, std::max(config_.maxCnt, 1), 0.01, (double)config_.minDist, st)) return -1;
+    reportFrame(st.n_tracked, st.n_detected, st.n_total);
     return st.n_total;
 }
 
@@ -79,6 +80,7 @@ void OpenVINSAdapter::configKey(const std::string&, const std::string& key, cons
 int OpenVINSAdapter::feedImage(const ImageView& image, int64_t, const std::vector<IMUSample>&) {
     if (config_.numFeatures <= 0) { corners_.clear(); return 0; }
     if (!frontEnd_.detectShiTomasi(image, config_.numFeatures, 0.01, (double)config_.minPxDist, corners_)) return -1;
+    reportFrame(0, (int)(corners_.size() / 2), (int)(corners_.size() / 2));
     return (int)(corners_.size() / 2);
 }
 
@@ -159,6 +161,7 @@ int BasaltAdapter::feedImage(const ImageView& image, int64_t, const std::vector<
     if (config_.maxFlowPoints <= 0) { corners_.clear(); return 0; }
     if (!frontEnd_.detectShiTomasi(image, config_.maxFlowPoints, config_.flowQualityThreshold * 0.01,
                                    (double)config_.minDistance, corners_)) return -1;
+    reportFrame(0, (int)(corners_.size() / 2), (int)(corners_.size() / 2));
     return (int)(corners_.size() / 2);
 }
 
@@ -240,6 +243,7 @@ int ORBSLAM3Adapter::feedImage(const ImageView& image, int64_t, const std::vecto
     /* cv::ORB::create(nFeatures): every other parameter at OpenCV's default, as the reference passes none */
     if (!frontEnd_.orbExtract(image, config_.nFeatures, 1.2f, 8, 20, keypoints_, descriptors_)) return -1;
     const int tracked = (int)keypoints_.size();
+    reportFrame(0, tracked, tracked);
     if (trackingState_ == TrackingState::NOT_INITIALIZED && frameCount_ >= 10 && tracked > 100) trackingState_ = TrackingState::OK;
     if (trackingState_ == TrackingState::OK) {
         if (tracked < 30) trackingState_ = TrackingState::RECENTLY_LOST;

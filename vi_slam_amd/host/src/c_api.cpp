@@ -11,7 +11,8 @@ using namespace vi_slam;
 namespace {
 struct Handle {
     SLAMEngine engine;
-    long poseCalls = 0, statusCalls = 0;
+    long poseCalls = 0, statusCalls = 0, statsCalls = 0;
+    std::string json;
     int lastStatus = 0;
     std::string err;
 };
@@ -23,6 +24,7 @@ void* vis_engine_create() {
     Handle* h = new Handle;
     h->engine.setPoseCallback([h](const Pose6DoF&) { h->poseCalls++; });
     h->engine.setStatusCallback([h](TrackingStatus s) { h->statusCalls++; h->lastStatus = (int)s; });
+    h->engine.setFrontEndStatsCallback([h](const FrontEndFrameStats&) { h->statsCalls++; });
     return h;
 }
 void vis_engine_destroy(void* p) { delete static_cast<Handle*>(p); }
@@ -53,6 +55,32 @@ int vis_engine_pose(void* p, double* out8) {
     std::memcpy(out8 + 4, pose.orientation, 4 * sizeof(double));
     return ok ? 1 : 0;
 }
+long vis_engine_stats_callbacks(void* p) { return static_cast<Handle*>(p)->statsCalls; }
+void vis_engine_enable_stage_timing(void* p, int on) { static_cast<Handle*>(p)->engine.enableStageTiming(on != 0); }
+/* out9: frames, failed frames, average latency us, P99 latency us, last frame's ok / tracked / detected / total / latency us;
+ * returns 1 once a frame has been recorded */
+int vis_engine_stats(void* p, double* out9) {
+    const FrontEndStats& st = static_cast<Handle*>(p)->engine.frontEndStats();
+    FrontEndFrameStats f;
+    const bool have = st.last(f);
+    out9[0] = (double)st.frames(); out9[1] = (double)st.failedFrames();
+    out9[2] = st.getAverageLatencyUs(); out9[3] = st.getP99LatencyUs();
+    out9[4] = f.ok ? 1.0 : 0.0; out9[5] = f.tracked; out9[6] = f.detected; out9[7] = f.total; out9[8] = f.latencyUs;
+    return have ? 1 : 0;
+}
+/* GPU time per stage of the last frame in microseconds (13 slots; zeros unless stage timing is on); returns 1 if present */
+int vis_engine_stage_us(void* p, double* out13) {
+    FrontEndFrameStats f;
+    const bool have = static_cast<Handle*>(p)->engine.frontEndStats().last(f);
+    for (int i = 0; i < kFrontEndStages; i++) out13[i] = have ? f.stageUs[i] : 0.0;
+    return have && f.haveStages ? 1 : 0;
+}
+const char* vis_engine_stats_json(void* p) {
+    Handle* h = static_cast<Handle*>(p);
+    h->json = h->engine.frontEndStats().toJSON();
+    return h->json.c_str();
+}
+void vis_engine_reset_latency_stats(void* p) { static_cast<Handle*>(p)->engine.frontEndStats().resetLatencyStats(); }
 int vis_engine_tracked_count(void* p) { return static_cast<Handle*>(p)->engine.getTrackedFeatureCount(); }
 long vis_engine_pose_callbacks(void* p) { return static_cast<Handle*>(p)->poseCalls; }
 long vis_engine_status_callbacks(void* p) { return static_cast<Handle*>(p)->statusCalls; }

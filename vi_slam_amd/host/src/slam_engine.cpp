@@ -1,5 +1,6 @@
 #include "slam/slam_engine.hpp"
 #include "common/logging.hpp"
+#include "vfe.h"
 #include "slam/adapters/basalt_adapter.hpp"
 #include "slam/adapters/openvins_adapter.hpp"
 #include "slam/adapters/orbslam3_adapter.hpp"
@@ -60,10 +61,40 @@ void SLAMEngine::processImage(const ImageView& image, int64_t timestampNs) {
     std::lock_guard<std::mutex> lock(frameworkMutex_);
     if (!framework_) { LOG_ERROR("SLAMEngine", "No framework available for image processing"); return; }
     if (!initialized_) { LOG_WARN("SLAMEngine", "Framework not initialized"); return; }
+    FrontEndFrameStats before;
+    const bool hadFrame = framework_->getLastFrameStats(before);
     framework_->processImage(image, timestampNs);
     Pose6DoF pose;
     if (framework_->getPose(pose) && pose.valid) invokePoseCallback(pose);
     invokeStatusCallback(framework_->getStatus());
+    /* a frame the adapter turned away at one of its guards (no calibration, IMU gate, empty image) never reached the
+     * front-end and leaves no record */
+    FrontEndFrameStats fs;
+    if (framework_->getLastFrameStats(fs) && (!hadFrame || fs.frameIndex != before.frameIndex)) {
+        if (stageTiming_) {
+            double ms[VFE_K_COUNT];
+            long long n[VFE_K_COUNT];
+            if (vfe_prof_read(ms, n, 1) == VFE_OK) {
+                fs.haveStages = true;
+                for (int i = 0; i < kFrontEndStages; i++) fs.stageUs[i] = ms[i] * 1e3;
+            }
+        }
+        stats_.record(fs);
+        std::lock_guard<std::mutex> cb(callbackMutex_);
+        if (statsCallback_) statsCallback_(fs);
+    }
+}
+
+void SLAMEngine::setFrontEndStatsCallback(FrontEndStatsCallback callback) {
+    std::lock_guard<std::mutex> lock(callbackMutex_);
+    statsCallback_ = std::move(callback);
+}
+
+void SLAMEngine::enableStageTiming(bool on) {
+    std::lock_guard<std::mutex> lock(frameworkMutex_);
+    stageTiming_ = on;
+    (void)vfe_prof_enable(on ? 1 : 0);
+    if (on) (void)vfe_prof_read(nullptr, nullptr, 1);
 }
 
 void SLAMEngine::processIMU(const IMUSample& imu) {
