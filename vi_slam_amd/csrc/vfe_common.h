@@ -50,6 +50,20 @@ struct ProfScope {
     ~ProfScope() { if (on) vfe_prof_end(id, st); }
 };
 
+/* A helper stream of the library (one per host thread and device) for independent kernels that run beside the caller's
+ * stream, forked from it and joined back into it with the two events.  Once forked, every way out of the entry point --
+ * error returns included -- must leave the caller's stream waiting for the helper: the caller may free or reuse its
+ * buffers as soon as it has the status code.  ForkGuard does that on scope exit unless the join has been made. */
+struct AuxStream { hipStream_t s; hipEvent_t fork, join; };
+AuxStream* vfe_aux_stream();
+bool vfe_overlap_on();
+struct ForkGuard {
+    AuxStream* a; hipStream_t st; bool joined;
+    ~ForkGuard() {
+        if (a && !joined && hipEventRecord(a->join, a->s) == hipSuccess) (void)hipStreamWaitEvent(st, a->join, 0);
+    }
+};
+
 /* plain-data view of one batched image, passed to kernels by value */
 struct DImg {
     uint8_t* data;

@@ -167,8 +167,7 @@ extern "C" size_t vfe_frontend_workspace(int width, int height, int batch, int m
 }
 
 /* helper stream + fork/join events, one set per host thread and device, created on first use */
-struct AuxStream { hipStream_t s; hipEvent_t fork, join; };
-static AuxStream* aux_stream() {
+AuxStream* vfe_aux_stream() {
     static thread_local AuxStream pool[32];
     static thread_local bool made[32];
     int dev = 0;
@@ -182,20 +181,13 @@ static AuxStream* aux_stream() {
     }
     return &pool[dev];
 }
-/* Once the helper stream has been forked, every way out of the step -- error returns included -- must leave the caller's
- * stream waiting for it: the caller may free or reuse the workspace and the frame as soon as it has its status code. */
-struct ForkGuard {
-    AuxStream* a; hipStream_t st; bool joined;
-    ~ForkGuard() {
-        if (a && !joined && hipEventRecord(a->join, a->s) == hipSuccess) (void)hipStreamWaitEvent(st, a->join, 0);
-    }
-};
-/* Detector and tracker side by side.  Both kernels are bound by vector-instruction issue, yet their waves fill each
- * other's stalls and tails: measured gain 6-11 % of the step from one stream to 256.  On by default for every batch
- * size; vfe_set_overlap(0) or VFE_OVERLAP=0 in the environment keeps everything on the caller's stream (e.g. to time the
- * kernels one at a time). */
+/* Independent kernels side by side.  The big kernels of the library are bound by vector-instruction issue, yet the waves
+ * of two of them fill each other's stalls and tails: the detector's eigenvalue pass beside pyramid + tracker gains 6-11 %
+ * of a front-end step from one stream to 256, the ORB blur beside FAST + selection likewise.  On by default for every
+ * batch size; vfe_set_overlap(0) or VFE_OVERLAP=0 in the environment keeps everything on the caller's stream (e.g. to time
+ * the kernels one at a time). */
 static std::atomic<int> g_overlap{-1}; /* -1: not set yet, take the environment's word */
-static bool fe_overlap() {
+bool vfe_overlap_on() {
     int m = g_overlap.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("VFE_OVERLAP");
@@ -244,7 +236,7 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
      * pyramids, so they run side by side -- the first half on a helper stream forked from the caller's stream here and
      * joined before the selection. */
     hipStream_t st = (hipStream_t)stream;
-    AuxStream* aux = fe_overlap() ? aux_stream() : nullptr;
+    AuxStream* aux = vfe_overlap_on() ? vfe_aux_stream() : nullptr;
     ForkGuard guard{nullptr, st, false};
     if (aux) {
         VFE_HIP(hipEventRecord(aux->fork, st));
