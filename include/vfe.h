@@ -256,6 +256,21 @@ int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const vfe_dimg* ne
                                  int win, int max_iter, double eps, double min_eig_thr,
                                  void* workspace, size_t workspace_bytes, const vfe_reject_opts* reject, void* stream);
 
+/* The step with OpenVINS's own detector in place of Shi-Tomasi: tracks are carried by KLT (`use_klt: true`, reference
+ * config/openvins.yaml:26) and the frame is refilled with FAST corners bucketed over a grid_x x grid_y grid (`fast_threshold`,
+ * `grid_x`, `grid_y`, `min_px_dist`, `num_pts`: config/openvins.yaml:29-37; struct fields
+ * include/slam/adapters/openvins_adapter.hpp:29-32) -- the keys the reference parses and then ignores in favour of one
+ * goodFeaturesToTrack call per frame (src/slam/adapters/openvins_adapter.cpp:78-80).  Steps 1-3 as vfe_dev_frontend_step,
+ * then vfe_dev_fast_grid with the surviving tracks as seeds and num_features = max_corners; the new points are appended
+ * in the order the grid offers them (cell by cell, best score first) until max_corners is reached.
+ * workspace: vfe_frontend_fast_workspace(...) bytes, 256-byte aligned. */
+size_t vfe_frontend_fast_workspace(int width, int height, int batch, int max_corners, int grid_x, int grid_y, int min_px_dist);
+int vfe_dev_frontend_step_fast(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                               float* pts, int* n_pts, int* n_tracked, int max_corners,
+                               int fast_threshold, int grid_x, int grid_y, int min_px_dist,
+                               int win, int max_iter, double eps, double min_eig_thr,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- kernel timing (HIP events recorded around every kernel the library launches) ------- */
 enum { VFE_K_PYR_DOWN = 0, VFE_K_GFTT_EIG, VFE_K_GFTT_SELECT, VFE_K_KLT, VFE_K_COMPACT, VFE_K_APPEND,
        VFE_K_FAST, VFE_K_ORB_RESIZE, VFE_K_ORB_BLUR, VFE_K_ORB_SELECT, VFE_K_ORB_DESC, VFE_K_MATCH,
@@ -383,6 +398,13 @@ int vfe_reset(vfe_ctx* ctx);
 #define VFE_EQ_HIST 1
 #define VFE_EQ_CLAHE 2
 int vfe_set_equalize(vfe_ctx* ctx, int mode);
+
+/* Detector behind vfe_process_frame: VFE_DET_SHI_TOMASI (default; quality / min_distance arguments of the call) or
+ * VFE_DET_FAST_GRID (OpenVINS's: FAST with `fast_threshold` on a grid_x x grid_y grid, occupancy cells of the call's
+ * min_distance rounded down to whole pixels; the call's quality argument is unused).  Switching forgets the stream. */
+#define VFE_DET_SHI_TOMASI 0
+#define VFE_DET_FAST_GRID 1
+int vfe_set_detector(vfe_ctx* ctx, int mode, int fast_threshold, int grid_x, int grid_y);
 
 /* vfe_process_frame filters tracks with the epipolar constraint before refilling (see vfe_reject_opts):
  * threshold <= 0 turns it off (default).  camera4 / dist5 may be NULL (raw pixel coordinates). */

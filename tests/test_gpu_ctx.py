@@ -228,3 +228,35 @@ def test_fast_grid_bit_exact(cuda, w, h, gx, gy, n, d):
         assert cnt[i] == len(rxy), f"frame {i}: {cnt[i]} vs {len(rxy)}"
         assert np.array_equal(pts[i, :cnt[i]], rxy) and np.array_equal(sc[i, :cnt[i]], rsc)
         assert cnt[i] > 0
+
+
+def test_ctx_fast_grid_detector_stream(cuda):
+    """vfe_set_detector(VFE_DET_FAST_GRID) + vfe_process_frame: the first frame is the grid detector alone, later frames
+    KLT + FAST-grid refill; equal to the oracle's composition bit for bit, and switching back restores Shi-Tomasi."""
+    w, h, cap, levels = 640, 480, 150, 3
+    thr, gx, gy, mpd = 15, 4, 3, 12
+    seq = [synth.scene(synth.BASE_SEED + 80, w, h, t) for t in range(4)]
+    ctx = capi.Context(w, h, max_features=cap, pyramid_levels=levels, win_size=21, orb_levels=0)
+    ctx.set_detector("fast_grid", thr, gx, gy)
+    ref = np.zeros((0, 2), np.float32)
+    for t, f in enumerate(seq):
+        n_tr, n_det, n_tot = ctx.process_frame(f, 10**9 + t * 33_000_000, cap, 0.01, float(mpd))
+        if t == 0:
+            ref, _ = ora.fast_grid(f, thr, gx, gy, cap, mpd)
+            ref, want_tr = ref[:cap], 0
+        else:
+            out, st, _ = ora.klt_track(seq[t - 1], f, ref, 21, levels - 1)
+            r = np.rint(out)
+            keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < w - 1) & (r[:, 1] >= 1) & (r[:, 1] < h - 1)
+            tracked = out[keep]
+            new, _ = ora.fast_grid(f, thr, gx, gy, cap, mpd, seeds=tracked)
+            new = new[:max(0, cap - len(tracked))]
+            ref, want_tr = (np.concatenate([tracked, new]) if len(new) else tracked), len(tracked)
+        assert (n_tr, n_tot) == (want_tr, len(ref)) and n_det == len(ref) - want_tr, (t, n_tr, n_det, n_tot, len(ref))
+        assert np.array_equal(ctx.points().view(np.uint32), ref.view(np.uint32)), f"frame {t}"
+    assert len(ref) > 60
+    ctx.set_detector("shi_tomasi")
+    n_tr, n_det, n_tot = ctx.process_frame(seq[0], 2 * 10**9, cap, 0.01, 12.0)
+    want, _ = ora.good_features(seq[0], cap, 0.01, 12.0)
+    assert n_tr == 0 and n_tot == len(want) and np.array_equal(ctx.points(), want)
+    ctx.close()

@@ -97,6 +97,37 @@ def test_vins_mono_stream_tracks_and_refills(cuda, tmp_path):
     e.close()
 
 
+def test_openvins_tracking_front_end(cuda, tmp_path):
+    """`gpu_frontend: track`: the OpenVINS keys the reference parses and ignores (use_klt, fast_threshold, grid_x, grid_y,
+    min_px_dist, num_klt_levels) drive KLT + FAST-grid refill through the adapter; per-frame point sets equal the oracle's
+    composition, and the statistics observer sees tracked / new counts."""
+    frames = [synth.scene(synth.BASE_SEED + 55, W, H, t) for t in range(4)]
+    e = make_engine(tmp_path, eng.OPENVINS, OPENVINS_YAML + "gpu_frontend: track\n")
+    lat, counts = eng.run_streaming(e, frames[:1])
+    ref, _ = ora.fast_grid(frames[0], 20, 5, 5, 200, 10)
+    ref = ref[:200]
+    assert e.frontend_error() == "" and counts[0] == len(ref) and np.array_equal(e.points(), ref)
+    t_ns = 2_000_000_000
+    for t in range(1, 4):
+        t_ns += 100_000_000
+        for k in range(10):
+            e.process_imu(t_ns - 100_000_000 + (k + 1) * 10_000_000, (0.0, 0.0, 9.81), (0.0, 0.0, 0.01))
+        e.process_image(frames[t], t_ns)
+        out, st, _ = ora.klt_track(frames[t - 1], frames[t], ref, 21, 2)
+        r = np.rint(out)
+        keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < W - 1) & (r[:, 1] >= 1) & (r[:, 1] < H - 1)
+        tracked = out[keep]
+        new, _ = ora.fast_grid(frames[t], 20, 5, 5, 200, 10, seeds=tracked)
+        new = new[:max(0, 200 - len(tracked))]
+        ref = np.concatenate([tracked, new]) if len(new) else tracked
+        assert e.tracked_count() == len(ref)
+        assert np.array_equal(e.points().view(np.uint32), ref.view(np.uint32)), f"frame {t}"
+        st_ = e.stats()
+        assert st_["ok"] and st_["tracked"] == len(tracked) and st_["detected"] == len(ref) - len(tracked)
+    assert e.frontend_error() == ""
+    e.close()
+
+
 def test_frontend_stats_reach_the_observer(cuda, tmp_path):
     """Egress: per-frame tracked / detected / total, latency window and per-stage GPU times through the engine's
     statistics observer, consistent with what the adapter itself reports."""

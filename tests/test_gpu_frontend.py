@@ -513,3 +513,58 @@ def test_frontend_step_with_epipolar_filter(cuda, camera):
             assert n_tr[b] == len(tracked), f"t={t} b={b}: {n_tr[b]} vs {len(tracked)} tracked"
             assert n_pts[b] == len(ref[b]) and np.array_equal(pts[b, :n_pts[b]].view(np.uint32), ref[b].view(np.uint32)), f"t={t} b={b}"
     assert rejected >= 5, "the filter never rejected anything: the test does not exercise it"
+
+
+def _ref_fast_track_step(prev, cur, pts, cap, thr, gx, gy, mpd, levels):
+    """Oracle composition of vfe_dev_frontend_step_fast: LK, drop lost / out-of-rim tracks, FAST-grid refill with the
+    survivors as seeds, append until `cap`."""
+    h, w = cur.shape
+    if len(pts):
+        out, st, _ = ora.klt_track(prev, cur, pts, 21, levels - 1)
+        r = np.rint(out)
+        keep = st.astype(bool) & (r[:, 0] >= 1) & (r[:, 0] < w - 1) & (r[:, 1] >= 1) & (r[:, 1] < h - 1)
+        tracked = out[keep]
+    else:
+        tracked = np.zeros((0, 2), np.float32)
+    new, _ = ora.fast_grid(cur, thr, gx, gy, cap, mpd, seeds=tracked)
+    new = new[:max(0, cap - len(tracked))]
+    return (np.concatenate([tracked, new]) if len(new) else tracked), len(tracked)
+
+
+def test_frontend_step_fast_grid_bit_exact(cuda):
+    """KLT + FAST-grid refill (OpenVINS's scheme) on two streams for three steps, bit for bit against the oracle."""
+    import torch
+    w, h, cap, levels = 752, 480, 200, 3
+    thr, gx, gy, mpd = 20, 5, 5, 10
+    seqs = [[synth.scene(synth.BASE_SEED + 70 + s, w, h, t) for t in range(4)] for s in range(2)]
+    frames = []
+    for t in range(4):
+        f = capi.alloc_image(2, h, w, cuda)
+        f.copy_(torch.from_numpy(np.stack([seqs[0][t], seqs[1][t]])).to(cuda))
+        frames.append(f)
+    pyr = [capi.alloc_pyramid(frames[0], levels), capi.alloc_pyramid(frames[0], levels)]
+    capi.build_pyramid(pyr[0])
+    fe = capi.FrontendStepFast(2, h, w, cap, levels, 21, thr, gx, gy, mpd, device=cuda)
+    ref = []
+    for s in range(2):  # first frame: the grid detector alone, nothing occupied yet
+        p0, _ = ora.fast_grid(seqs[s][0], thr, gx, gy, cap, mpd)
+        p0 = p0[:cap]
+        ref.append(p0)
+        fe.pts[s, :len(p0)] = torch.from_numpy(p0).to(cuda)
+        fe.n_pts[s] = len(p0)
+        assert len(p0) > 100
+    cur = 0
+    for t in range(1, 4):
+        nxt = cur ^ 1
+        pyr[nxt][0] = frames[t]
+        fe.step(pyr[cur], pyr[nxt])
+        cur = nxt
+        got, got_n, got_t = fe.pts.cpu().numpy(), fe.n_pts.cpu().numpy(), fe.n_tracked.cpu().numpy()
+        for s in range(2):
+            ref[s], nt = _ref_fast_track_step(seqs[s][t - 1], seqs[s][t], ref[s], cap, thr, gx, gy, mpd, levels)
+            assert got_n[s] == len(ref[s]) and got_t[s] == nt, f"step {t} stream {s}: {got_n[s]} vs {len(ref[s])}"
+            assert np.array_equal(got[s, :got_n[s]].view(np.uint32), ref[s].view(np.uint32)), f"step {t} stream {s}"
+        # stream 1 loses a third of its tracks, so the next refill has real work
+        keep1 = int(got_n[1]) * 2 // 3
+        fe.n_pts[1] = keep1
+        ref[1] = ref[1][:keep1]

@@ -97,6 +97,17 @@ def test_front_end_keys_of_the_reference_yaml_files(tmp_path):
     e.close()
 
 
+def test_openvins_tracking_front_end_is_opt_in(tmp_path):
+    """`gpu_frontend: track` is this build's switch for OpenVINS's own scheme (KLT + FAST grid); without it the adapter
+    keeps the reference's behaviour whatever use_klt says."""
+    e = eng.SLAMEngine()
+    assert e.select_framework(eng.OPENVINS) and e.initialize(write(tmp_path, "a.yaml", OPENVINS_YAML))
+    assert e.config_value("trackFrontEnd") == 0 and e.config_value("useKLT") == 1
+    assert e.select_framework(eng.OPENVINS) and e.initialize(write(tmp_path, "b.yaml", OPENVINS_YAML + "gpu_frontend: track\n"))
+    assert e.config_value("trackFrontEnd") == 1
+    e.close()
+
+
 def test_engine_gates_like_the_reference(tmp_path):
     cfg = write(tmp_path, "ov.yaml", OPENVINS_YAML)
     cal = write(tmp_path, "calib.yaml", "cam0: {}\n")

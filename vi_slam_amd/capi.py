@@ -88,6 +88,10 @@ SIGNATURES = {
     "vfe_dev_frontend_step": (C.c_int, [_DI, _DI, C.c_int, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int,
                                         C.c_int, C.c_double, C.c_double, _P, C.c_size_t, _P]),
     "vfe_set_overlap": (C.c_int, [C.c_int]),
+    "vfe_frontend_fast_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfe_dev_frontend_step_fast": (C.c_int, [_DI, _DI, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_double, C.c_double, _P, C.c_size_t, _P]),
+    "vfe_set_detector": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vfe_prof_enable": (C.c_int, [C.c_int]),
     "vfe_prof_read": (C.c_int, [_P, _P, C.c_int]),
     "vfe_prof_kernel_name": (C.c_char_p, [C.c_int]),
@@ -377,6 +381,35 @@ class FrontendStep:
         return self.pts, self.n_pts, self.n_tracked
 
 
+class FrontendStepFast:
+    """Buffers + call wrapper for vfe_dev_frontend_step_fast (KLT + FAST-grid refill) on `batch` streams of h x w frames."""
+
+    def __init__(self, batch, h, w, max_corners, nlevels=4, win=21, fast_threshold=20, grid_x=5, grid_y=5, min_px_dist=10,
+                 max_iter=30, eps=0.01, min_eig_thr=1e-4, device="cuda"):
+        import torch
+        self.batch, self.h, self.w, self.cap, self.nlevels = batch, h, w, max_corners, nlevels
+        self.win, self.max_iter, self.eps, self.min_eig_thr = win, max_iter, eps, min_eig_thr
+        self.det = (fast_threshold, grid_x, grid_y, min_px_dist)
+        nbytes = lib().vfe_frontend_fast_workspace(w, h, batch, max_corners, grid_x, grid_y, min_px_dist)
+        if nbytes == 0:
+            raise VfeError("vfe_frontend_fast_workspace: invalid shape")
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.ws_bytes = nbytes
+        self.pts = torch.zeros((batch, max_corners, 2), dtype=torch.float32, device=device)
+        self.n_pts = torch.zeros(batch, dtype=torch.int32, device=device)
+        self.n_tracked = torch.zeros(batch, dtype=torch.int32, device=device)
+
+    def step(self, prev_levels, next_levels):
+        n = self.nlevels
+        pa = (DImg * n)(*[dimg(t) for t in prev_levels])
+        na = (DImg * n)(*[dimg(t) for t in next_levels])
+        thr, gx, gy, mpd = self.det
+        check(lib().vfe_dev_frontend_step_fast(pa, na, n, _ptr(self.pts), _ptr(self.n_pts), _ptr(self.n_tracked), self.cap, thr, gx, gy,
+                                               mpd, self.win, self.max_iter, self.eps, self.min_eig_thr, _ptr(self.ws), self.ws_bytes,
+                                               _stream()))
+        return self.pts, self.n_pts, self.n_tracked
+
+
 K_NAMES = None
 
 
@@ -585,6 +618,11 @@ class Context:
         cam = (C.c_double * 4)(*camera) if camera is not None else None
         d5 = (C.c_double * 5)(*dist) if camera is not None else None
         check(lib().vfe_set_f_rejection(self._h, float(threshold), cam, d5, float(virtual_focal)))
+
+    def set_detector(self, mode, fast_threshold=20, grid_x=5, grid_y=5):
+        """0 / "shi_tomasi" (default) or 1 / "fast_grid" (OpenVINS's FAST per grid cell) behind process_frame."""
+        m = {"shi_tomasi": 0, "fast_grid": 1}.get(mode, mode)
+        check(lib().vfe_set_detector(self._h, int(m), fast_threshold, grid_x, grid_y))
 
     def set_equalize(self, mode):
         """False/0 off, True/1 cv::equalizeHist, 2 or "clahe" CLAHE (clip 10, 8 x 8 tiles)."""

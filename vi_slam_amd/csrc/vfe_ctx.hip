@@ -28,6 +28,8 @@ struct vfe_ctx {
     void* mws; size_t mws_bytes;        /* growable: match descriptors + workspace */
     int cur, have_prev, w, h;           /* stream state */
     double f_thr, f_cam[4], f_dist[5], f_focal; int f_have_cam; void* f_ws; size_t f_ws_bytes; /* epipolar track filter */
+    int det_mode, det_thr, det_gx, det_gy; void* det_ws; size_t det_ws_bytes; int det_min_px; /* FAST-grid detector */
+    float* det_pts; int* det_scores; int det_cap;
     int equalize; unsigned* eq_hist;    /* optional histogram equalisation of every uploaded frame */
     /* pinned host memory: frames are repacked here row by row and leave in ONE contiguous copy (a pitched
      * copy from pageable memory is done row by row by the runtime, ~4 ms per MB); results come back
@@ -108,6 +110,7 @@ extern "C" void vfe_destroy(vfe_ctx* c) {
                     c->ws, c->orb_kps, c->orb_desc, c->mws, c->eq_hist};
     for (void* p : bufs) (void)hipFree(p);
     (void)hipFree(c->f_ws);
+    (void)hipFree(c->det_ws); (void)hipFree(c->det_pts); (void)hipFree(c->det_scores);
     (void)hipHostFree(c->h_stage[0]); (void)hipHostFree(c->h_stage[1]); (void)hipHostFree(c->h_io); (void)hipHostFree(c->h_small);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -214,6 +217,36 @@ extern "C" int vfe_set_f_rejection(vfe_ctx* c, double threshold, const double* c
     c->f_have_cam = camera4 ? 1 : 0;
     if (camera4) { memcpy(c->f_cam, camera4, sizeof(c->f_cam)); memcpy(c->f_dist, dist5, sizeof(c->f_dist)); c->f_focal = virtual_focal; }
     c->f_thr = threshold;
+    return VFE_OK;
+}
+
+extern "C" int vfe_set_detector(vfe_ctx* c, int mode, int fast_threshold, int grid_x, int grid_y) {
+    int rc = ctx_enter(c);
+    if (rc) return rc;
+    VFE_REQUIRE(mode == VFE_DET_SHI_TOMASI || mode == VFE_DET_FAST_GRID, "mode must be VFE_DET_SHI_TOMASI or VFE_DET_FAST_GRID");
+    if (mode == VFE_DET_FAST_GRID) {
+        VFE_REQUIRE(fast_threshold >= 1 && fast_threshold <= 254, "fast_threshold must be 1..254");
+        VFE_REQUIRE(grid_x > 0 && grid_y > 0 && grid_x * grid_y <= 4096, "grid must have 1..4096 cells");
+    }
+    VFE_HIP(hipStreamSynchronize(c->stream));
+    c->det_mode = mode; c->det_thr = fast_threshold; c->det_gx = grid_x; c->det_gy = grid_y;
+    c->have_prev = 0; c->cur = 0;
+    VFE_HIP(hipMemsetAsync(c->n_pts, 0, sizeof(int), c->stream));
+    return VFE_OK;
+}
+
+/* buffers of the FAST-grid detector, sized for the context's largest frame and the finest occupancy grid asked for so far */
+static int ctx_det_buffers(vfe_ctx* c, int min_px) {
+    const int cap2 = c->cfg.max_features + c->det_gx * c->det_gy + 16;
+    const size_t a = vfe_frontend_fast_workspace(c->cfg.max_width, c->cfg.max_height, 1, c->cfg.max_features, c->det_gx, c->det_gy, min_px);
+    if (c->det_ws && a <= c->det_ws_bytes && cap2 <= c->det_cap && min_px >= c->det_min_px) return VFE_OK;
+    VFE_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->det_ws); (void)hipFree(c->det_pts); (void)hipFree(c->det_scores);
+    c->det_ws = nullptr; c->det_pts = nullptr; c->det_scores = nullptr; c->det_ws_bytes = 0; c->det_cap = 0;
+    VFE_HIP(hipMalloc(&c->det_ws, a));
+    VFE_HIP(hipMalloc((void**)&c->det_pts, (size_t)cap2 * 2 * sizeof(float)));
+    VFE_HIP(hipMalloc((void**)&c->det_scores, (size_t)cap2 * sizeof(int)));
+    c->det_ws_bytes = a; c->det_cap = cap2; c->det_min_px = min_px;
     return VFE_OK;
 }
 
@@ -366,7 +399,27 @@ extern "C" int vfe_process_frame(vfe_ctx* c, const uint8_t* data, int rows, int 
     vfe_dimg pl[CTX_MAX_LK_LEVELS], nl[CTX_MAX_LK_LEVELS];
     const int nlev = ctx_levels(c, nxt, cols, rows, c->cfg.pyramid_levels - 1, nl);
     int h_n[2] = {0, 0};
-    if (!c->have_prev) {
+    if (c->det_mode == VFE_DET_FAST_GRID) {
+        const int min_px = (int)min_distance;
+        VFE_REQUIRE(min_px >= 1, "the FAST-grid detector needs min_distance >= 1 pixel");
+        VFE_REQUIRE(!(c->f_thr > 0), "the epipolar filter is not available with the FAST-grid detector");
+        if ((rc = ctx_det_buffers(c, min_px))) return rc;
+        if (!c->have_prev) {
+            if ((rc = vfe_dev_build_pyramid(nl, nlev, c->stream))) return rc;
+            /* first frame: every cell offers its best corners, nothing is occupied yet */
+            VFE_HIP(hipMemsetAsync(c->n_pts, 0, sizeof(int), c->stream));
+            const size_t gb = vfe_fast_grid_workspace(cols, rows, 1, c->det_gx, c->det_gy, min_px);
+            if ((rc = vfe_dev_fast_grid(&nl[0], c->det_thr, c->det_gx, c->det_gy, max_corners, min_px, nullptr, nullptr, 0,
+                                        c->det_pts, c->det_scores, c->det_cap, c->counts, c->det_ws, gb, c->stream))) return rc;
+            if ((rc = vfe_dev_append_points(c->pts, c->n_pts, max_corners, 1, c->det_pts, c->counts, c->det_cap, c->stream))) return rc;
+            VFE_HIP(hipMemsetAsync(c->n_tracked, 0, sizeof(int), c->stream));
+        } else {
+            ctx_levels(c, c->cur, cols, rows, c->cfg.pyramid_levels - 1, pl);
+            const size_t need = vfe_frontend_fast_workspace(cols, rows, 1, max_corners, c->det_gx, c->det_gy, min_px);
+            if ((rc = vfe_dev_frontend_step_fast(pl, nl, nlev, c->pts, c->n_pts, c->n_tracked, max_corners, c->det_thr, c->det_gx,
+                                                 c->det_gy, min_px, c->cfg.win_size, 30, 0.01, 1e-4, c->det_ws, need, c->stream))) return rc;
+        }
+    } else if (!c->have_prev) {
         if ((rc = vfe_dev_build_pyramid(nl, nlev, c->stream))) return rc;
         if ((rc = vfe_dev_good_features(&nl[0], max_corners, quality, min_distance, nullptr, nullptr, 0, c->pts, nullptr,
                                         c->n_pts, c->ws, c->ws_bytes, c->stream))) return rc;

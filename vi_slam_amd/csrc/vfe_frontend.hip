@@ -202,6 +202,64 @@ extern "C" int vfe_set_overlap(int mode) {
     return VFE_OK;
 }
 
+/* ---- the same step with OpenVINS's detector: FAST per grid cell instead of Shi-Tomasi ------------------------------------ */
+struct FeFastWs { size_t next_off, status_off, corners_off, scores_off, counts_off, order_off, grid_off, grid_bytes, total; int ccap; };
+static FeFastWs fe_fast_layout(int w, int h, int batch, int cap, int grid_x, int grid_y, int min_px_dist) {
+    FeFastWs L; size_t o = 0;
+    L.ccap = cap + grid_x * grid_y + 16; /* a cell may offer one point more than its share */
+    L.next_off = o; o += align_up((size_t)batch * cap * 2 * sizeof(float), 256);
+    L.status_off = o; o += align_up((size_t)batch * cap, 256);
+    L.corners_off = o; o += align_up((size_t)batch * L.ccap * 2 * sizeof(float), 256);
+    L.scores_off = o; o += align_up((size_t)batch * L.ccap * sizeof(int), 256);
+    L.counts_off = o; o += align_up((size_t)batch * sizeof(int), 256);
+    L.order_off = o; o += align_up((size_t)batch * cap * sizeof(unsigned short), 256);
+    L.grid_bytes = vfe_fast_grid_workspace(w, h, batch, grid_x, grid_y, min_px_dist);
+    L.grid_off = o; o += align_up(L.grid_bytes, 256);
+    L.total = o;
+    return L;
+}
+extern "C" size_t vfe_frontend_fast_workspace(int width, int height, int batch, int max_corners, int grid_x, int grid_y, int min_px_dist) {
+    if (width <= 0 || height <= 0 || batch <= 0 || max_corners <= 0 || grid_x <= 0 || grid_y <= 0 || min_px_dist <= 0) return 0;
+    return fe_fast_layout(width, height, batch, max_corners, grid_x, grid_y, min_px_dist).total;
+}
+
+extern "C" int vfe_dev_frontend_step_fast(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                                          float* pts, int* n_pts, int* n_tracked, int max_corners,
+                                          int fast_threshold, int grid_x, int grid_y, int min_px_dist,
+                                          int win, int max_iter, double eps, double min_eig_thr,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    VFE_REQUIRE(prev_levels && next_levels && nlevels >= 1 && nlevels <= 8, "nlevels must be 1..8");
+    VFE_REQUIRE(pts && n_pts && workspace, "NULL buffer");
+    VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+    VFE_REQUIRE(grid_x > 0 && grid_y > 0 && grid_x * grid_y <= 4096 && min_px_dist > 0 && max_corners > 0, "bad grid parameters");
+    int rc = vfe_check_dimg(&next_levels[0], "next level 0");
+    if (rc) return rc;
+    const int w = next_levels[0].width, h = next_levels[0].height, batch = next_levels[0].batch, cap = max_corners;
+    const FeFastWs L = fe_fast_layout(w, h, batch, cap, grid_x, grid_y, min_px_dist);
+    if (workspace_bytes < L.total) {
+        vfe_set_error("workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+        return VFE_E_NOMEM;
+    }
+    char* ws = (char*)workspace;
+    float* next_pts = (float*)(ws + L.next_off);
+    uint8_t* status = (uint8_t*)(ws + L.status_off);
+    float* corners = (float*)(ws + L.corners_off);
+    int* scores = (int*)(ws + L.scores_off);
+    int* counts = (int*)(ws + L.counts_off);
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = vfe_dev_build_pyramid(next_levels, nlevels, stream))) return rc;
+    unsigned short* order = (cap <= 65536 && (long long)batch * cap >= 16384) ? (unsigned short*)(ws + L.order_off) : nullptr;
+    if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, order, st))) return rc;
+    if ((rc = klt_track_ordered(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
+                                win, max_iter, eps, min_eig_thr, 0, order, st))) return rc;
+    if ((rc = vfe_dev_compact_tracks(next_pts, status, n_pts, cap, batch, w, h, 1, pts, n_pts, stream))) return rc;
+    if (n_tracked) VFE_HIP(hipMemcpyAsync(n_tracked, n_pts, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, st));
+    /* the surviving tracks mark the occupancy grid; every cell then offers its best corners */
+    if ((rc = vfe_dev_fast_grid(&next_levels[0], fast_threshold, grid_x, grid_y, max_corners, min_px_dist, pts, n_pts, cap,
+                                corners, scores, L.ccap, counts, ws + L.grid_off, L.grid_bytes, stream))) return rc;
+    return vfe_dev_append_points(pts, n_pts, cap, batch, corners, counts, L.ccap, stream);
+}
+
 extern "C" int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
                                      float* pts, int* n_pts, int* n_tracked, int max_corners,
                                      double quality, double min_distance,

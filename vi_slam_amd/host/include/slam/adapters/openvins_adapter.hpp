@@ -20,10 +20,16 @@ struct OpenVINSConfig {
     double imuInitWindow = 1.0;
     int maxImuWaiting = 3;
     int numKltLevels = 3;  /* num_klt_levels (config/openvins.yaml:39); the reference has no parser for it */
+    /* `gpu_frontend: track` (a key of this build, absent from the reference's files): make use_klt / fast_threshold /
+     * grid_x / grid_y / min_px_dist / num_klt_levels drive the front-end they describe -- KLT tracking with a FAST-grid
+     * refill, OpenVINS's own scheme -- instead of the reference adapter's one goodFeaturesToTrack call per frame, which
+     * stays the default (`gpu_frontend: detect`) */
+    bool trackFrontEnd = false;
 };
 
 /* OpenVINS adapter: feedImage is goodFeaturesToTrack(gray, numFeatures, 0.01, minPxDist) as at
- * src/slam/adapters/openvins_adapter.cpp:59-86, computed on the GPU. */
+ * src/slam/adapters/openvins_adapter.cpp:59-86, computed on the GPU; with `gpu_frontend: track` and `use_klt: true` it is
+ * pyramidal KLT of the previous frame's points plus a FAST-grid refill (vfe_process_frame with VFE_DET_FAST_GRID). */
 class OpenVINSAdapter : public AdapterBase {
 public:
     OpenVINSAdapter();
@@ -33,6 +39,7 @@ public:
 
 protected:
     void configKey(const std::string& section, const std::string& key, const std::string& value) override;
+    void configDone() override;
     double imuInitWindow() const override { return config_.imuInitWindow; }
     int feedImage(const ImageView& image, int64_t timestampNs, const std::vector<IMUSample>& imu) override;
     bool estimatePose(Pose6DoF& pose, int64_t timestampNs) override;

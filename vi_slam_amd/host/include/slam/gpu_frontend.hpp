@@ -25,6 +25,9 @@ public:
     /* epipolar outlier filter between tracking and refill (`F_threshold`, config/vins_mono.yaml:101); threshold <= 0: off;
      * camera4 / dist5 may be null (raw pixel coordinates) */
     void setFRejection(double threshold, const double* camera4, const double* dist5, double virtualFocal);
+    /* detector behind processFrame: Shi-Tomasi (default) or OpenVINS's FAST per grid cell (`fast_threshold`, `grid_x`,
+     * `grid_y`: config/openvins.yaml:29-33) */
+    void setFastGridDetector(bool on, int fastThreshold, int gridX, int gridY);
     /* each returns false and records lastError() on failure; never throws */
     bool detectShiTomasi(const ImageView& img, int maxCorners, double quality, double minDistance, std::vector<float>& xy);
     bool orbExtract(const ImageView& img, int nFeatures, float scaleFactor, int nLevels, int fastThreshold,
@@ -43,6 +46,8 @@ private:
     int equalize_ = 0;
     double fThr_ = 0, fCam_[4] = {0, 0, 0, 0}, fDist_[5] = {0, 0, 0, 0, 0}, fFocal_ = 460.0;
     bool fHaveCam_ = false;
+    bool detFast_ = false;
+    int detThr_ = 20, detGx_ = 5, detGy_ = 5;
     std::string error_;
 };
 

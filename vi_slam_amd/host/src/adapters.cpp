@@ -75,10 +75,25 @@ void OpenVINSAdapter::configKey(const std::string&, const std::string& key, cons
     else if (key == "max_msckf_update") config_.maxMsckfUpdate = std::stoi(value);
     else if (key == "use_zupt" || key == "use_zero_velocity_update") config_.useZeroVelocityUpdate = parseBool(value);
     else if (key == "imu_init_window") config_.imuInitWindow = std::stod(value);
+    else if (key == "gpu_frontend") config_.trackFrontEnd = (value == "track" || value == "\"track\"");
 }
 
-int OpenVINSAdapter::feedImage(const ImageView& image, int64_t, const std::vector<IMUSample>&) {
+void OpenVINSAdapter::configDone() {
+    const bool track = config_.trackFrontEnd && config_.useKLT;
+    const int levels = std::max(1, std::min(8, config_.numKltLevels));
+    frontEnd_.configure(std::max(config_.numFeatures, 1), track ? levels : 4, 21, 0);
+    frontEnd_.setFastGridDetector(track, config_.fastThreshold, config_.gridX, config_.gridY);
+}
+
+int OpenVINSAdapter::feedImage(const ImageView& image, int64_t timestampNs, const std::vector<IMUSample>&) {
     if (config_.numFeatures <= 0) { corners_.clear(); return 0; }
+    if (config_.trackFrontEnd && config_.useKLT) {
+        vfe_frame_stats st{0, 0, 0};
+        if (!frontEnd_.processFrame(image, timestampNs, config_.numFeatures, 0.01, (double)config_.minPxDist, st)) return -1;
+        frontEnd_.points(corners_);
+        reportFrame(st.n_tracked, st.n_detected, st.n_total);
+        return st.n_total;
+    }
     if (!frontEnd_.detectShiTomasi(image, config_.numFeatures, 0.01, (double)config_.minPxDist, corners_)) return -1;
     reportFrame(0, (int)(corners_.size() / 2), (int)(corners_.size() / 2));
     return (int)(corners_.size() / 2);

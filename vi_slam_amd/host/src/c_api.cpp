@@ -117,6 +117,7 @@ int vis_engine_config_value(void* p, const char* key, double* out) {
         else if (k == "fastThreshold") *out = c.fastThreshold; else if (k == "gridX") *out = c.gridX;
         else if (k == "gridY") *out = c.gridY; else if (k == "useKLT") *out = c.useKLT;
         else if (k == "imuInitWindow") *out = c.imuInitWindow; else if (k == "numKltLevels") *out = c.numKltLevels;
+        else if (k == "trackFrontEnd") *out = c.trackFrontEnd;
         else return 0;
         return 1;
     }

@@ -38,6 +38,14 @@ void GpuFrontEnd::setFRejection(double threshold, const double* camera4, const d
     }
 }
 
+void GpuFrontEnd::setFastGridDetector(bool on, int fastThreshold, int gridX, int gridY) {
+    detFast_ = on; detThr_ = fastThreshold; detGx_ = gridX; detGy_ = gridY;
+    if (ctx_) {
+        const int rc = vfe_set_detector(ctx_, on ? VFE_DET_FAST_GRID : VFE_DET_SHI_TOMASI, detThr_, detGx_, detGy_);
+        if (rc != VFE_OK) { release(); (void)fail(rc); }
+    }
+}
+
 void GpuFrontEnd::release() {
     if (ctx_) { vfe_destroy(ctx_); ctx_ = nullptr; }
 }
@@ -59,6 +67,10 @@ bool GpuFrontEnd::ensure(const ImageView& img) {
      * with the option silently off */
     const int rcE = vfe_set_equalize(ctx_, equalize_);
     if (rcE != VFE_OK) { release(); return fail(rcE); }
+    if (detFast_) {
+        const int rcD = vfe_set_detector(ctx_, VFE_DET_FAST_GRID, detThr_, detGx_, detGy_);
+        if (rcD != VFE_OK) { release(); return fail(rcD); }
+    }
     if (fThr_ > 0) {
         const int rcF = vfe_set_f_rejection(ctx_, fThr_, fHaveCam_ ? fCam_ : nullptr, fHaveCam_ ? fDist_ : nullptr, fFocal_);
         if (rcF != VFE_OK) { release(); return fail(rcF); }
