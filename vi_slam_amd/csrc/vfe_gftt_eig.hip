@@ -39,6 +39,12 @@ __device__ static inline float max3(float a, float b, float c) {
     return d;
 }
 
+__device__ static inline float min2(float a, float b) { /* no NaNs here: one instruction, no quieting */
+    float d;
+    asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 template <bool WRITE_MAP, bool ALIGNED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
                                                   float* __restrict__ eigmap, u32* __restrict__ frame_max,
@@ -53,6 +59,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     u64* stage = s_stage[wv];
     const u64 lt_mask = (1ull << lane) - 1ull;
     const bool out_lane = lane >= 2 && lane < 62;
+    const u64 inner_lanes = 0x7FFFFFFFFFFFFFFEull; /* lanes 1..62 */
 
     for (unsigned work = wave; work < total_work; work += nwaves) {
         const int b = work % img.batch, t_item = work / img.batch;
@@ -64,10 +71,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint8_t* ip = img.frame(b);
         u32 seen = 0;
         float prune = 0.f, wmax = 0.f;
+        float prune_half = -1.f; /* rows whose every min(a, c) is <= this are skipped (negative: none) */
         if (!WRITE_MAP) {
             seen = __hip_atomic_load(&frame_max[b * GF_CSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             wmax = __uint_as_float(seen);
             prune = (float)((double)wmax * quality);
+            prune_half = prune * 0.5f - 2e-7f;
         }
         int nbuf = 0;
         const int seg = t_item % GF_NSEG;
@@ -96,6 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         f2 RX[3][2], RY[3][2];   /* Sobel row filters of image rows yy-2, yy-1, yy */
         f2 HS[3][3][2];          /* [slot][plane][pair]: horizontal sums of product rows P-2, P-1, P */
         f2 EG[3][2], HM[3][2];   /* eigenvalue rows E-2, E-1, E and their horizontal 3-maxima */
+        bool dead_row[3] = {false, false, false}; /* wave-uniform: the slot's eigenvalue row was skipped (see below) */
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -168,27 +178,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             {
                 const int E = yy - 2;
                 const bool yin = !YB || (E >= 0 && E < H);
+                f2 a_[2], c_[2], xy_[2], s_[2];
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
                     const f2 sxx = (HS[s2][0][p] + HS[s1][0][p]) + HS[s0][0][p];
-                    const f2 sxy = (HS[s2][1][p] + HS[s1][1][p]) + HS[s0][1][p];
+                    xy_[p] = (HS[s2][1][p] + HS[s1][1][p]) + HS[s0][1][p];
                     const f2 syy = (HS[s2][2][p] + HS[s1][2][p]) + HS[s0][2][p];
-                    const f2 a = sxx * 0.5f, cc = syy * 0.5f;
-                    const f2 d = a - cc;
-                    const f2 q = d * d + sxy * sxy;
-                    const f2 rt = sqrt_rn2(q);
-                    f2 e = (a + cc) - rt;
-                    if (!yin) e = f2{-1.f, -1.f};
-                    if (EDGE) {
-                        if (!xin[2 * p]) e.x = -1.f;
-                        if (!xin[2 * p + 1]) e.y = -1.f;
-                    }
-                    EG[s0][p] = e;
+                    a_[p] = sxx * 0.5f; c_[p] = syy * 0.5f;
+                    s_[p] = a_[p] + c_[p];
                 }
-                const f2 e01 = EG[s0][0], e23 = EG[s0][1];
-                const float l = lane_up(e23.y), r = lane_down(e01.x);
-                HM[s0][0] = f2{max3(l, e01.x, e01.y), max3(e01.x, e01.y, e23.x)};
-                HM[s0][1] = f2{max3(e01.y, e23.x, e23.y), max3(e23.x, e23.y, r)};
+                /* A row in which no pixel of the wave can pass the quality threshold needs neither the square roots nor a
+                 * place in the maximum or the candidate test.  The smaller eigenvalue is at most 2 min(a, c); as computed
+                 * here (five roundings) at most 2 min(a, c) + 5 * 2^-24 (a + c), and a + c <= 1 for 8-bit pixels (|Sobel| <=
+                 * 1020 / 3060 per component, nine products per sum, halved).  Rows with min(a, c) <= prune / 2 - 2e-7 for
+                 * every pixel of lanes 1..62 (lanes 0 and 63 hold incomplete sums and feed nothing) are given -1 instead.
+                 * prune <= the frame maximum seen so far, so such a row can neither raise the maximum nor hold a candidate,
+                 * and as a neighbour in the 3x3 test any value <= prune loses against a candidate (> prune) exactly as the
+                 * true one would.  Steady-state rows of the candidate pass only. */
+                bool dead = false;
+                if constexpr (!WRITE_MAP && !YB) {
+                    const float tm = max3(max3(min2(a_[0].x, c_[0].x), min2(a_[0].y, c_[0].y), min2(a_[1].x, c_[1].x)),
+                                          min2(a_[1].y, c_[1].y), 0.f);
+                    dead = (__ballot(tm > prune_half) & inner_lanes) == 0;
+                }
+                dead_row[s0] = dead;
+                if (dead) {
+                    EG[s0][0] = EG[s0][1] = HM[s0][0] = HM[s0][1] = f2{-1.f, -1.f};
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const f2 d = a_[p] - c_[p];
+                        const f2 q = d * d + xy_[p] * xy_[p];
+                        const f2 rt = sqrt_rn2(q);
+                        f2 e = s_[p] - rt;
+                        if (!yin) e = f2{-1.f, -1.f};
+                        if (EDGE) {
+                            if (!xin[2 * p]) e.x = -1.f;
+                            if (!xin[2 * p + 1]) e.y = -1.f;
+                        }
+                        EG[s0][p] = e;
+                    }
+                    const f2 e01 = EG[s0][0], e23 = EG[s0][1];
+                    const float l = lane_up(e23.y), r = lane_down(e01.x);
+                    HM[s0][0] = f2{max3(l, e01.x, e01.y), max3(e01.x, e01.y, e23.x)};
+                    HM[s0][1] = f2{max3(e01.y, e23.x, e23.y), max3(e23.x, e23.y, r)};
+                }
             }
             if constexpr (ST < 4) return;
             /* ---- output row N = yy - 3: value EG[s1], neighbourhood maxima HM[s2], HM[s1], HM[s0] ---- */
@@ -202,6 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
                 return;
             }
+            if (dead_row[s1]) return; /* nothing above prune in this row: no maximum to raise, no candidate */
             wmax = max3(wmax, max3(v[0], v[1], v[2]), v[3]);
             if (N < 1 || N > H - 2) return;
             const float m[4] = {max3(HM[s2][0].x, HM[s1][0].x, HM[s0][0].x), max3(HM[s2][0].y, HM[s1][0].y, HM[s0][0].y),
@@ -249,6 +284,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             step(ic<0>{}, ic<4>{}, nyb, t0);
             step(ic<1>{}, ic<4>{}, nyb, t0 + 1);
             step(ic<2>{}, ic<4>{}, nyb, t0 + 2);
+            if constexpr (!WRITE_MAP) {
+                /* Every 24 rows the wave shares what it knows about the frame maximum: all waves of a launch that fits on
+                 * the chip at once start blind (maximum 0, nothing pruned, no row skipped), and the maximum only reaches
+                 * memory when a wave ends.  Publishing the running maximum and reading the frame's back gives every wave
+                 * a threshold close to the final one after its first rows.  Any lower bound of the final maximum is a
+                 * valid pruning value: the selection applies the exact threshold afterwards. */
+                if ((t0 - 6) % 24 == 21) {
+                    float wm = out_lane ? wmax : 0.f;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+                    if (lane == 0 && __float_as_uint(wm) > seen) atomicMax(&frame_max[b * GF_CSTRIDE], __float_as_uint(wm));
+                    const u32 now = __hip_atomic_load(&frame_max[b * GF_CSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seen = max(max(seen, now), __float_as_uint(wm)); /* positive floats order like their bit patterns */
+                    wmax = fmaxf(wmax, __uint_as_float(seen));
+                    prune = (float)((double)__uint_as_float(seen) * quality);
+                    prune_half = prune * 0.5f - 2e-7f;
+                }
+            }
         }
         /* at most two steps left of the loop's range and two beyond it */
         if (t0 < T) step(ic<0>{}, ic<4>{}, yb, t0);
