@@ -19,7 +19,7 @@ SLOTS = {
     "k_klt": ("k_klt21", ["k_klt21"]),
     "k_compact": ("k_compact", ["k_compact"]),
     "k_append": ("k_append", ["k_append"]),
-    "k_fast": ("k_fast_stream", ["k_fast_stream", "k_fast_scan_stream", "k_fast_scatter_stream"]),
+    "k_fast": ("k_fast_queue", ["k_fast_queue", "k_fast_scan_stream", "k_fast_scatter_stream"]),
     "k_orb_resize": ("k_orb_tables", ["k_orb_tables", "k_orb_resize_rows", "k_orb_resize"]),
     "k_orb_blur": ("k_orb_blur", ["k_orb_blur"]),
     "k_orb_select": ("k_orb_hist", ["k_orb_hist", "k_orb_harris", "k_orb_thresh", "k_orb_emit"]),

@@ -5,23 +5,32 @@
  * One wavefront owns a strip of 62 x 4 columns (lanes 0 and 63 are halo) and walks down a band of rows.
  * A lane keeps the last seven image rows as three dwords each (its own four bytes and the neighbours'),
  * so every pixel of the 16-pixel circle is a byte of a register.  Two horizontally adjacent pixels are
- * scored together in packed 16-bit arithmetic:
+ * handled together in packed 16-bit arithmetic.
+ *
+ * Per row every lane evaluates only a necessary condition on the four compass pixels (each opposite pair
+ * must hold a pixel that differs from the centre by more than t).  It passes for a few percent of the
+ * pixel pairs (3 % on a full-resolution level of a typical frame, a third on the coarsest ORB level), yet
+ * nearly every 248-pixel row holds some, so a wave-wide skip of the 9-arc evaluation would almost never
+ * fire.  Instead the pairs that pass are queued (row, lane, pair) in LDS; whenever 64 are waiting, every
+ * lane takes one, reads its 7 x 12-byte window from a ring of the wave's last image rows in LDS and scores
+ * it:
  *   score = max(t, max over 9-arcs of min(d), -min over 9-arcs of max(d)) - 1,   d = centre - circle,
  * a pixel is a corner iff the bracket exceeds t.  The sixteen 9-arc minima come from suffix minima of
  * d[k..7], d[k..15] and prefix minima of d[0..k], d[8..k]: arc k..k+8 is one suffix plus the prefix
- * eight places on (28 + 16 operations instead of 64 by doubling).  Before that, a necessary condition
- * on the four compass pixels (each opposite pair must hold a pixel that differs from the centre by more
- * than t) is evaluated for the whole wave: if no lane passes, the pair is skipped.  Scores of three rows
- * stay in registers for the 3x3 suppression; keypoints of a row segment are numbered in raster order
- * with ballots and written to the segment's slot together with the segment's count.
+ * eight places on (28 + 16 operations instead of 64 by doubling).  The two scores go to a ring of score
+ * rows in LDS.  Suppression and output of a row follow FQ_K rows behind its compass test, reading the
+ * score ring; a candidate older than that is scored at once even if fewer than 64 are waiting.  Scores of
+ * three rows stay in registers for the 3x3 suppression; keypoints of a row segment are numbered in raster
+ * order with ballots and written to the segment's slot together with the segment's count.
  *
- * The row loop is unrolled seven times so that the image ring's slots are compile-time constants; a
- * band is 7k - 8 rows high so that every wave runs whole periods. */
+ * The row loop is unrolled seven times so that the image ring's register slots are compile-time constants;
+ * a band is 7k - 8 rows high so that every wave runs whole periods. */
 #include "vfe_common.h"
 #include "vfe_fast.h"
 #include <type_traits>
 
 typedef unsigned int u32;
+typedef unsigned long long u64;
 typedef short s2v __attribute__((ext_vector_type(2)));
 typedef unsigned short u2v __attribute__((ext_vector_type(2)));
 template <int N> using ic = std::integral_constant<int, N>;
@@ -45,29 +54,36 @@ __device__ static inline s2v win_pair(const u32 (&row)[3], int i) {
 #define FS_DY(k) ((k) == 0 ? 3 : (k) == 1 ? 3 : (k) == 2 ? 2 : (k) == 3 ? 1 : (k) == 4 ? 0 : (k) == 5 ? -1 : (k) == 6 ? -2 : (k) == 7 ? -3 : \
                   (k) == 8 ? -3 : (k) == 9 ? -3 : (k) == 10 ? -2 : (k) == 11 ? -1 : (k) == 12 ? 0 : (k) == 13 ? 1 : (k) == 14 ? 2 : 3)
 
-/* scores of the pixel pair (px, px+1) of the centre row; px = 0 or 2 within the lane's four pixels.  The ring
+#define FQ_K 8               /* rows between the compass test of a row and its suppression */
+#define FQ_IR 16             /* image ring (>= FQ_K + 7: rows c-3 of the oldest queued centre c .. the row being loaded); a power of two */
+#define FQ_SR 16             /* score ring (>= FQ_K + 2: from a row's compass test to its last use as a neighbour); a power of two */
+#define FQ_AHEAD 7           /* image rows requested ahead: a row step is a few hundred cycles, a trip to HBM thousands */
+#define FQ_QCAP 256          /* queue entries (63 left over + one row's 128 at most) */
+static_assert(FQ_IR >= FQ_K + 7 && FQ_SR >= FQ_K + 2 && (FQ_IR & (FQ_IR - 1)) == 0 && (FQ_SR & (FQ_SR - 1)) == 0 && FQ_IR <= 32 && FQ_SR <= 16,
+              "ring sizes: powers of two that cover the delay, and ring slots must fit the 5 + 4 bits of a queue entry");
+static_assert(FQ_AHEAD == 7, "the prefetch ring shares the period of the unrolled row loop");
+
+/* necessary condition on the compass pixels of the pair (PX, PX+1): true if either pixel can be a corner.  The ring
  * slot PH holds the newest row (centre + 3), so centre + dy sits in slot (PH + 4 + dy) mod 7. */
 template <int PX, int PH>
-__device__ static inline u32 fast_score_pair(const u32 (&R)[7][3], int t) {
+__device__ static inline bool fast_compass_pair(const u32 (&R)[7][3], int t, u32 sm) {
 #define FS_ROW(dy) R[(PH + 4 + (dy) + 7) % 7]
     const s2v v = win_pair(FS_ROW(0), PX + 4);
+    const s2v d0 = v - win_pair(FS_ROW(FS_DY(0)), PX + FS_DX(0) + 4), d4 = v - win_pair(FS_ROW(FS_DY(4)), PX + FS_DX(4) + 4);
+    const s2v d8 = v - win_pair(FS_ROW(FS_DY(8)), PX + FS_DX(8) + 4), d12 = v - win_pair(FS_ROW(FS_DY(12)), PX + FS_DX(12) + 4);
+#undef FS_ROW
+    const s2v a0 = pmax(d0, splat(0) - d0), a8 = pmax(d8, splat(0) - d8);
+    const s2v a4 = pmax(d4, splat(0) - d4), a12 = pmax(d12, splat(0) - d12);
+    const s2v m = pmin(pmax(a0, a8), pmax(a4, a12));
+    return (m.x > (short)t && (sm & 0xFFFFu)) || (m.y > (short)t && (sm >> 16));
+}
+
+/* scores of the pixel pair at bytes 4, 5 of the 12-byte windows R[0..6] (centre row R[3]); no shortcut */
+__device__ static inline u32 fast_score_window(const u32 (&R)[7][3], int t) {
+    const s2v v = win_pair(R[3], 4);
     s2v d[16];
 #pragma unroll
-    for (int k = 0; k < 16; k += 4) d[k] = v - win_pair(FS_ROW(FS_DY(k)), PX + FS_DX(k) + 4);
-    bool pass;
-    {   /* compass pixels first: a 9-arc holds one pixel of each opposite pair */
-        const s2v a0 = pmax(d[0], splat(0) - d[0]), a8 = pmax(d[8], splat(0) - d[8]);
-        const s2v a4 = pmax(d[4], splat(0) - d[4]), a12 = pmax(d[12], splat(0) - d[12]);
-        const s2v m = pmin(pmax(a0, a8), pmax(a4, a12));
-        pass = m.x > (short)t || m.y > (short)t;
-    }
-    if (__ballot(pass) == 0) return 0u;
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (k & 3) d[k] = v - win_pair(FS_ROW(FS_DY(k)), PX + FS_DX(k) + 4);
-#undef FS_ROW
-    /* arc k .. k+8 = d[k .. end of its half] (a suffix extremum, kept running) and d[start of the other half .. k+8]
-     * (a prefix extremum of the other half) */
+    for (int k = 0; k < 16; k++) d[k] = v - win_pair(R[3 + FS_DY(k)], FS_DX(k) + 4);
     s2v a = splat(-32768), b = splat(32767);
 #pragma unroll
     for (int h = 0; h < 16; h += 8) {
@@ -84,16 +100,21 @@ __device__ static inline u32 fast_score_pair(const u32 (&R)[7][3], int t) {
             b = pmin(b, pmax(rx, px[j]));
         }
     }
-    const s2v m = pmax(pmax(a, splat(t)), splat(0) - pmin(b, splat(-t))); /* >= t; > t iff corner */
+    const s2v m = pmax(pmax(a, splat(t)), splat(0) - pmin(b, splat(-t)));
     const s2v e = m - splat(t);
-    /* score = m - 1 for corners, 0 otherwise */
     return as_u(pmin(e, splat(1)) * (e + splat(t - 1)));
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_stream(FastSet S, int threshold, int border, uint8_t* __restrict__ rowcnt, u32* __restrict__ tmp) {
-    const int lane = threadIdx.x & 63;
-    const unsigned wave = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4u; /* wave-uniform */
+/* One wave per workgroup: items differ in length with their share of candidates, and a workgroup's LDS is held until
+ * its slowest wave ends. */
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_queue(FastSet S, int threshold, int border, uint8_t* __restrict__ rowcnt, u32* __restrict__ tmp) {
+    __shared__ u32 img_ring[FQ_IR][64];
+    __shared__ u32 sc_ring[FQ_SR][64];
+    __shared__ unsigned short queue[FQ_QCAP];
+    const int lane = threadIdx.x;
+    const unsigned wave = blockIdx.x, nwaves = gridDim.x; /* wave-uniform */
     const unsigned total_work = S.item_begin[S.n];
+    const u64 lt_mask = (1ull << lane) - 1ull;
     for (unsigned work = wave; work < total_work; work += nwaves) {
         int lv = 0;
         while (lv + 1 < S.n && work >= S.item_begin[lv + 1]) lv++;
@@ -107,7 +128,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int X0 = sxi * FS_OUT + 4 * (lane - 1); /* image column of this lane's pixel 0 */
         const int y0 = byi * band_h;
         const uint8_t* ip = img.data + (size_t)b * img.fstride;
-        const bool fast_load = img.aligned && X0 >= 0 && X0 + 3 < W;
+        /* with dword-aligned rows every lane loads one dword: bytes left of column 0 or right of column W - 1 feed no
+         * scored pixel, and a dword that starts inside the row ends inside its pitch */
+        const int X0c = min(max(X0, 0), (W - 1) & ~3);
         const bool out_lane = lane >= 1 && lane < 63;
         const size_t seg0 = (size_t)S.seg_begin[lv] + (size_t)b * H * strips_x + sxi;
         /* per pixel: may be scored (circle inside the image), may be reported */
@@ -116,58 +139,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = X0 + k;
+            /* the halo lanes score too: pixel 3 of lane 0 and pixel 0 of lane 63 are neighbours in the suppression */
             if (x >= 3 && x < W - 3) smask[k >> 1] |= 0xFFFFu << (16 * (k & 1));
             rep[k] = out_lane && x >= border && x < W - border;
         }
 
         u32 R[7][3]; /* image rows: left neighbour's, own, right neighbour's dword; the row of step t in slot t mod 7 */
-        u32 SC[3][3]; /* score rows N-2 .. N: pixel pairs (0,1), (2,3) as 16-bit values, and s[-1] | s[4] << 16 */
+        u32 SC[3][3]; /* score rows M-1 .. M+1: pixel pairs (0,1), (2,3) as 16-bit values, and s[-1] | s[4] << 16 */
 #pragma unroll
         for (int i = 0; i < 7; i++) R[i][0] = R[i][1] = R[i][2] = 0;
 #pragma unroll
         for (int i = 0; i < 3; i++) SC[i][0] = SC[i][1] = SC[i][2] = 0;
+        int qn = 0, q_head = 0, first_c = 0; /* queue state (wave-uniform); first_c = centre index of the oldest entry */
 
-        /* the lane's four pixels of image row yy; rows and columns outside the image are never part of a scored
-         * circle: clamp */
         auto load_row = [&](int yy) -> u32 {
             const uint8_t* row = ip + (size_t)min(max(yy, 0), H - 1) * img.pitch;
-            if (fast_load) return *reinterpret_cast<const uint32_t*>(row + X0);
+            if (img.aligned) return *reinterpret_cast<const uint32_t*>(row + X0c); /* wave-uniform */
             return (u32)row[min(max(X0, 0), W - 1)] | ((u32)row[min(max(X0 + 1, 0), W - 1)] << 8) |
                    ((u32)row[min(max(X0 + 2, 0), W - 1)] << 16) | ((u32)row[min(max(X0 + 3, 0), W - 1)] << 24);
         };
-        u32 pre = load_row(y0 - 4);
+        u32 pre[FQ_AHEAD]; /* rows y0 - 4 + t .. + 6 on their way; the row of step t sits in slot t mod 7 */
+#pragma unroll
+        for (int i = 0; i < FQ_AHEAD; i++) pre[i] = load_row(y0 - 4 + i);
 
-        /* stc: 0 = load only, 1 = also score row yy - 3, 2 = also (if t >= 8) report row yy - 4 */
-        auto step = [&](auto phc, auto stc, int t) {
-            constexpr int PH = decltype(phc)::value, ST = decltype(stc)::value;
-            const int yy = y0 - 4 + t;
-            {
-                /* the row was requested a step ago; request the next one now (clamped: always a valid address) */
-                const u32 c = pre;
-                pre = load_row(yy + 1);
-                R[PH][1] = c;
-                R[PH][0] = lane_up_u(c);
-                R[PH][2] = lane_down_u(c);
+        /* Rows are counted in steps: step t loads image row y0 - 4 + t; index c names the row loaded in step c. */
+        /* score up to 64 queued pairs: lane i takes entry q_head + i */
+        auto drain = [&](int tc_now) {
+            const int n = min(qn, 64);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const u32 e = queue[(q_head + lane) & (FQ_QCAP - 1)];
+            const bool act = lane < n;
+            const int pair = (int)(e & 1u), L = act ? (int)((e >> 1) & 63u) : 1, srow = (int)((e >> 7) & 15u);
+            const int cslot = act ? (int)(e >> 11) : 3;
+            u32 Rq[7][3];
+            const u32 sh = (u32)pair << 4; /* the pair at bytes 6, 7 of its lane's window moves to bytes 4, 5 */
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const u32* p = img_ring[(cslot + i - 3) & (FQ_IR - 1)];
+                const u32 wl = p[max(L - 1, 0)], wc = p[L], wr = p[min(L + 1, 63)]; /* lanes 0 and 63: their outer pixels feed nothing */
+                Rq[i][0] = __builtin_amdgcn_alignbit(wc, wl, sh);
+                Rq[i][1] = __builtin_amdgcn_alignbit(wr, wc, sh);
+                Rq[i][2] = wr >> sh;
             }
-            if constexpr (ST < 1) return;
-            /* ---- scores of row N = yy - 3 ---- */
-            const int N = yy - 3;
+            u32 s = fast_score_window(Rq, threshold);
+            /* pixels whose circle leaves the image score 0 */
+            const int x = sxi * FS_OUT + 4 * (L - 1) + 2 * pair;
+            if (!(x >= 3 && x < W - 3)) s &= 0xFFFF0000u;
+            if (!(x + 1 >= 3 && x + 1 < W - 3)) s &= 0x0000FFFFu;
+            if (act) reinterpret_cast<unsigned short*>(&sc_ring[srow][0])[2 * L + pair] = (unsigned short)((s & 0xFFu) | ((s >> 8) & 0xFF00u));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            q_head = (q_head + n) & (FQ_QCAP - 1);
+            qn -= n;
+            if (qn > 0) { /* centre index of the new oldest entry, from its ring slot */
+                const int hs = __builtin_amdgcn_readfirstlane((int)queue[q_head] >> 11);
+                first_c = tc_now - ((tc_now - hs) & (FQ_IR - 1));
+            }
+        };
+        /* everything older than FQ_K rows, and whole batches of 64 */
+        auto drain_due = [&](int t) {
+            while (qn >= 64 || (qn > 0 && first_c <= t - 3 - FQ_K)) drain(t - 3);
+        };
+        /* suppression and output of row index m = t - 4 - FQ_K (image row M); scores of rows <= m + 1 are final */
+        auto suppress = [&](int t, int n_rows) {
+            const int cn = t - 3 - FQ_K; /* newest score row needed */
 #pragma unroll
             for (int i = 0; i < 2; i++) { SC[i][0] = SC[i + 1][0]; SC[i][1] = SC[i + 1][1]; SC[i][2] = SC[i + 1][2]; }
             {
                 u32 s01 = 0, s23 = 0;
-                if (N >= 3 && N < H - 3) { /* wave-uniform */
-                    s01 = fast_score_pair<0, PH>(R, threshold) & smask[0];
-                    s23 = fast_score_pair<2, PH>(R, threshold) & smask[1];
+                if (cn >= 3 && cn < n_rows) { /* rows that went through the compass test (wave-uniform) */
+                    const u32 w4 = sc_ring[cn & (FQ_SR - 1)][lane];
+                    s01 = __builtin_amdgcn_perm(0u, w4, 0x0c010c00u);
+                    s23 = __builtin_amdgcn_perm(0u, w4, 0x0c030c02u);
                 }
                 SC[2][0] = s01; SC[2][1] = s23;
                 const u32 sl = lane_up_u(s23) >> 16, sr = lane_down_u(s01) & 0xFFFFu;
                 SC[2][2] = sl | (sr << 16);
             }
-            if constexpr (ST < 2) return;
-            /* ---- suppression and output of row M = yy - 4 (score rows M-1, M, M+1 = SC[0], SC[1], SC[2]) ---- */
-            const int M = yy - 4;
-            if (t < 8 || M >= H) return; /* wave-uniform */
+            const int m = cn - 1, M = y0 - 4 + m;
+            if (m < 4 || M >= H || M >= y0 + band_h) return; /* wave-uniform */
             int total = 0;
             if (__ballot((SC[1][0] | SC[1][1]) != 0) != 0 && M >= border && M < H - border) {
                 u2v nb01, nb23; /* largest of the eight neighbours */
@@ -211,16 +260,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (lane == 0) rowcnt[seg0 + (size_t)M * strips_x] = (uint8_t)total;
         };
 
-        /* image rows y0-4 .. y0+band_h+3, band_h + 8 = whole periods of seven steps; rows past the image are
-         * loaded clamped, scored as 0 and not reported */
+        const int T = band_h + 8; /* load steps; rows with a compass test have indices 3 .. T - 4 */
+        /* stc: 0 = load only, 1 = also the compass test of row index t - 3, 2 = also drain what is due and suppress */
+        auto step = [&](auto phc, auto stc, int t) {
+            constexpr int PH = decltype(phc)::value, ST = decltype(stc)::value;
+            const int yy = y0 - 4 + t;
+            {
+                const u32 c = pre[PH];
+                pre[PH] = load_row(yy + FQ_AHEAD); /* clamped: always a valid address */
+                R[PH][1] = c;
+                R[PH][0] = lane_up_u(c);
+                R[PH][2] = lane_down_u(c);
+                img_ring[t & (FQ_IR - 1)][lane] = c;
+            }
+            if constexpr (ST < 1) return;
+            const int tc = t - 3, N = yy - 3;
+            sc_ring[tc & (FQ_SR - 1)][lane] = 0u;
+            if (N >= 3 && N < H - 3) { /* wave-uniform */
+                const bool p0 = fast_compass_pair<0, PH>(R, threshold, smask[0]);
+                const bool p1 = fast_compass_pair<2, PH>(R, threshold, smask[1]);
+                const u64 m0 = __ballot(p0), m1 = __ballot(p1);
+                const int n0 = __popcll(m0), n1 = __popcll(m1);
+                if (n0 + n1) {
+                    const u32 base = ((u32)(tc & (FQ_IR - 1)) << 11) | ((u32)(tc & (FQ_SR - 1)) << 7) | ((u32)lane << 1);
+                    const int tail = q_head + qn;
+                    if (p0) queue[(tail + __popcll(m0 & lt_mask)) & (FQ_QCAP - 1)] = (unsigned short)base;
+                    if (p1) queue[(tail + n0 + __popcll(m1 & lt_mask)) & (FQ_QCAP - 1)] = (unsigned short)(base | 1u);
+                    if (qn == 0) first_c = tc;
+                    qn += n0 + n1;
+                }
+            }
+            if constexpr (ST < 2) return;
+            drain_due(t);
+            suppress(t, T - 3);
+        };
+
         step(ic<0>{}, ic<0>{}, 0); step(ic<1>{}, ic<0>{}, 1); step(ic<2>{}, ic<0>{}, 2); step(ic<3>{}, ic<0>{}, 3);
         step(ic<4>{}, ic<0>{}, 4); step(ic<5>{}, ic<0>{}, 5); step(ic<6>{}, ic<1>{}, 6);
-        const int T = band_h + 8;
-        for (int t0 = 7; t0 < T; t0 += 7) {
-            if (y0 - 4 + t0 - 4 >= H) break; /* nothing left to report (wave-uniform) */
+        int t0 = 7;
+        for (; t0 < T; t0 += 7) {
+            if (y0 - 7 + t0 >= H - 3) break; /* no row left that could be scored (wave-uniform) */
             step(ic<0>{}, ic<2>{}, t0); step(ic<1>{}, ic<2>{}, t0 + 1); step(ic<2>{}, ic<2>{}, t0 + 2); step(ic<3>{}, ic<2>{}, t0 + 3);
             step(ic<4>{}, ic<2>{}, t0 + 4); step(ic<5>{}, ic<2>{}, t0 + 5); step(ic<6>{}, ic<2>{}, t0 + 6);
         }
+        /* the rows still on their way: no more loads, only what is queued and the suppression behind it.  Score rows of
+         * indices >= t0 - 3 never had a compass test: suppress() reads them as 0. */
+        const int t_end = min(band_h, H - y0) + 8 + FQ_K;
+        for (int t = t0; t < t_end; t++) {
+            drain_due(t);
+            suppress(t, t0 - 3);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the next item reuses the rings */
     }
 }
 
@@ -325,8 +415,8 @@ int fast_detect_set(FastSet& S, int batch, int threshold, int border, char* ws, 
     uint8_t* rowcnt = (uint8_t*)(ws + L.rowcnt_off);
     u32* rowoff = (u32*)(ws + L.rowoff_off);
     u32* tmp = (u32*)(ws + L.tmp_off);
-    const unsigned total = S.item_begin[S.n], nblk = (total + 3) / 4, n_seg = S.seg_begin[S.n];
-    hipLaunchKernelGGL(k_fast_stream, dim3(nblk < (1u << 20) ? nblk : (1u << 20)), dim3(256), 0, st, S, threshold, border, rowcnt, tmp);
+    const unsigned total = S.item_begin[S.n], n_seg = S.seg_begin[S.n];
+    hipLaunchKernelGGL(k_fast_queue, dim3(total < (1u << 22) ? total : (1u << 22)), dim3(64), 0, st, S, threshold, border, rowcnt, tmp);
     VFE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_fast_scan_stream, dim3(batch, S.n), dim3(1024), 0, st, S, rowcnt, rowoff);
     VFE_LAUNCH_CHECK();
