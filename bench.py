@@ -47,7 +47,9 @@ VALU_CYCLES_PER_INST, SIMDS, CLOCK_GHZ = 4.2, 1024, 2.4
 # average issue cost of a kernel's instruction mix where it is known to differ: the matcher spends 8 of its 19 instructions per
 # pair on 2.2-cycle xors.  For the others 4.2 is used for every instruction, which overstates the time at the ceiling (and so
 # the fraction of it reached) by whatever share of their instructions belongs to the 2.2-cycle classes.
-VALU_CYCLES_BY_KERNEL = {"k_match": (8 * 2.2 + 11 * 4.2) / 19}
+VALU_CYCLES_BY_KERNEL = {}
+MFMA_FP4_PEAK_TFLOPS = 10000.0   # dense block-scaled fp4 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), the matcher's instruction
+MATCH_FLOP_PER_PAIR = 512        # one descriptor pair = a 256-element product of +-1 vectors
 
 # algorithmic bytes per 1080p frame (each distinct input byte once + each API-visible output byte once)
 BYTES_PYR = 2073600 + 518400 + 129600 + 32400               # read L0, write L1..L3
@@ -252,13 +254,27 @@ def load_counters():
         return {}
 
 
-def roofline_for(kernels, counters, leg, batch):
-    """`roofline` object for the kernel with the largest share of the leg's timed region."""
+def roofline_for(kernels, counters, leg, batch, flop_per_step=None, steps=1):
+    """`roofline` object for the kernel with the largest share of the leg's timed region.  `flop_per_step`: arithmetic per
+    step of the kernel slots that run on the matrix cores; such a slot is priced against the MFMA peak."""
     scored = {k: v for k, v in kernels.items() if v["algo_GBs"]}
     if not scored:
         return None
     dom = max(scored, key=lambda k: scored[k]["share"])
     k = scored[dom]
+    if flop_per_step and dom in flop_per_step:
+        sec_per_step = k["avg_ms"] * 1e-3 * k["launches"] / steps
+        ach = flop_per_step[dom] / sec_per_step / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / MFMA_FP4_PEAK_TFLOPS, "traffic": None, "algo_flop_per_step": flop_per_step[dom],
+                "launches_per_step": k["launches"] / steps, "avg_launch_ms": k["avg_ms"],
+                "algo_GBs": k["algo_GBs"],
+                "note": "fp4 operands (+1 / -1 per descriptor bit), fp32 accumulation: 512 flop per descriptor pair"}
+        c = counters.get("legs", {}).get(leg, {})
+        if c.get("batch") == batch and dom in c.get("kernels", {}):
+            roof["traffic"] = c["kernels"][dom].get("total_bytes")
+            roof["traffic_source"] = f"profiles/traffic.json ({counters.get('tag', '')})"
+        return roof
     roof = {"kernel": dom, "bound": "hbm", "achieved": k["algo_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": k["algo_GBs"] / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": k["algo_bytes_per_launch"],
             "avg_launch_ms": k["avg_ms"]}
@@ -484,7 +500,7 @@ def run_reloc_leg(rk, steps, warmup, counters):
     per_step = {"k_match": 32 * (N_QUERIES + rows) + 16 * N_QUERIES}
     kernels = kernel_table(prof, elapsed, per_step, steps)
     pairs = N_QUERIES * MAP_ROWS * steps
-    roof = roofline_for(kernels, counters, "reloc", rows)
+    roof = roofline_for(kernels, counters, "reloc", rows, {"k_match": MATCH_FLOP_PER_PAIR * N_QUERIES * rows}, steps)
     out = {"workload": f"configs[4]: {N_QUERIES} query descriptors against a {MAP_ROWS}-row 256-bit map, rows sharded over "
                        f"{rk.world} GPU(s), per-shard top-2 all-gathered (32 000 B per rank) and merged",
            "value": N_QUERIES * steps / elapsed, "unit": "queries/s", "ms_per_query_set": elapsed / steps * 1e3, "steps": steps,

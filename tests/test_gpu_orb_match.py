@@ -125,7 +125,9 @@ def test_orb_quotas_and_sizes_match_oracle():
     assert list(ora.orb_quotas(2000)) == [434, 362, 302, 251, 209, 175, 145, 122]
 
 
-@pytest.mark.parametrize("nq,nt", [(2000, 2000), (300, 5000), (64, 1), (5, 0), (257, 70000)])
+@pytest.mark.parametrize("nq,nt", [(2000, 2000), (300, 5000), (64, 1), (5, 0), (257, 70000),
+                                   # every number of query tiles per wave, partial query blocks, partial and single train tiles
+                                   (1025, 3000), (513, 40), (2049, 33), (100, 31), (100, 32), (100, 33), (2000, 65), (1, 2), (256, 257)])
 def test_match_knn2_bit_exact(cuda, nq, nt):
     import torch
     q = synth.descriptors(1, nq)
@@ -141,6 +143,34 @@ def test_match_knn2_bit_exact(cuda, nq, nt):
     assert np.array_equal(dist.cpu().numpy(), rdist)
     good = capi.ratio_test(idx, dist, 0.7).cpu().numpy()
     assert np.array_equal(good, ora.ratio_test(ridx, rdist, 0.7))
+
+
+@pytest.mark.parametrize("random_head", [False, True])
+def test_match_knn2_large_set_with_ties(cuda, random_head):
+    """A train set large enough for the sample-then-floor search (>= 500 000 rows), built from 48 distinct descriptors so
+    that every distance is tied thousands of times across the sample boundary and across chunks: the result is the
+    oracle's ascending scan with strict '<' (lowest index wins).  With `random_head` the sampled rows are unrelated
+    random descriptors, so the floor they give is far from the final distances."""
+    import torch
+    nq, nt, head = 300, 520_000, 40_000
+    base = synth.descriptors(5, 48)
+    rng = np.random.default_rng(3 + random_head)
+    t = base[rng.integers(0, 48, nt)].copy()
+    if random_head:
+        t[:head] = synth.descriptors(6, head)
+    q = base[rng.integers(0, 48, nq)].copy()
+    for i in range(nq):
+        q[i] = synth.flip_bits(900 + i, q[i], i % 7)
+    idx, dist = capi.match_knn2(torch.from_numpy(q).to(cuda), torch.from_numpy(t).to(cuda), base_index=7)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    sel = np.arange(0, nq, 13)
+    ridx, rdist = ora.match_knn2(q[sel], t, 7)
+    assert np.array_equal(idx[sel], ridx) and np.array_equal(dist[sel], rdist)
+    # every query: its two neighbours are the two lowest rows holding its base descriptor
+    assert (dist[:, 0] == dist[:, 1]).all() and (dist[:, 0] == np.arange(nq) % 7).all()
+    assert (idx[:, 0] < idx[:, 1]).all()
+    if random_head:
+        assert (idx[:, 0] >= head + 7).all()
 
 
 def test_match_knn2_batch_equals_per_pair_calls(cuda):

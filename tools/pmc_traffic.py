@@ -24,7 +24,7 @@ SLOTS = {
     "k_orb_blur": ("k_orb_blur", ["k_orb_blur"]),
     "k_orb_select": ("k_orb_hist", ["k_orb_hist", "k_orb_harris", "k_orb_thresh", "k_orb_emit"]),
     "k_orb_desc": ("k_orb_desc", ["k_orb_desc"]),
-    "k_match": (None, ["k_match", "k_match_batch"]),  # one of the two per leg, one dispatch per scope
+    "k_match": (None, ["k_match_mm", "k_match_mm_batch"]),  # one of the two per leg, one dispatch per scope
 }
 LEG_SLOTS = {"main": ["k_pyr_down", "k_gftt_eig", "k_gftt_select", "k_klt", "k_compact", "k_append"],
              "streams64": ["k_pyr_down", "k_gftt_eig", "k_gftt_select", "k_klt", "k_compact", "k_append"],
@@ -48,7 +48,7 @@ def per_kernel(root, counter):
 def slot_value(vals, slot, leg):
     anchor, kernels = SLOTS[slot]
     if slot == "k_match":
-        kernels = ["k_match_batch"] if leg == "orb_match" else ["k_match"]
+        kernels = ["k_match_mm_batch"] if leg == "orb_match" else ["k_match_mm"]
         anchor = kernels[0]
     if not vals.get(anchor):
         return None, 0

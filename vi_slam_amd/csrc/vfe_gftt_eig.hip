@@ -45,14 +45,17 @@ __device__ static inline float min2(float a, float b) { /* no NaNs here: one ins
     return d;
 }
 
+#ifndef EV_WPB
+#define EV_WPB 4 /* waves per workgroup */
+#endif
 template <bool WRITE_MAP, bool ALIGNED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
+__global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
                                                   float* __restrict__ eigmap, u32* __restrict__ frame_max,
                                                   u32* __restrict__ cand_count, u64* __restrict__ cand, u32 seg_cap,
                                                   double quality, int band_mod, int band_sel) {
-    __shared__ u64 s_stage[4][EV_STAGE];
+    __shared__ u64 s_stage[EV_WPB][EV_STAGE];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* wave-uniform: row counters and addresses stay scalar */
-    const unsigned wave = blockIdx.x * 4u + wv, nwaves = gridDim.x * 4u;
+    const unsigned wave = blockIdx.x * (unsigned)EV_WPB + wv, nwaves = gridDim.x * (unsigned)EV_WPB;
     const int W = img.w, H = img.h;
     const double scale = 1.0 / ((1 << 2) * 3 * 255.0);
     const float k_o = (float)scale, k_c = (float)(2.0 * scale);
@@ -333,13 +336,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_count, u64* cand, u32 seg_cap,
                      double quality, hipStream_t st) {
     const EigGeom g = eig_geom(d.w, d.h, d.batch);
-    const unsigned nblk = (g.total + 3) / 4;
+    const unsigned nblk = (g.total + EV_WPB - 1) / EV_WPB;
     /* one item per wave: items are tens of microseconds long and few per wave, so handing them
      * out through the dispatcher balances better than persistent waves with a fixed stride */
-    dim3 grid(nblk < (1u << 20) ? nblk : (1u << 20));
+    dim3 grid(nblk < (1u << 22) ? nblk : (1u << 22));
     const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
     if (eigmap) {
-        hipLaunchKernelGGL((k_gftt_eig<true, false>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+        hipLaunchKernelGGL((k_gftt_eig<true, false>), grid, dim3(64 * EV_WPB), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
                            eigmap, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, 0u, 0.0, 0, 0);
         return;
     }
@@ -351,10 +354,10 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
     for (int pass = two_pass ? 1 : 0; pass >= 0; pass--) {
         const int mod = two_pass ? 8 : 0;
         if (aligned)
-            hipLaunchKernelGGL((k_gftt_eig<false, true>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+            hipLaunchKernelGGL((k_gftt_eig<false, true>), grid, dim3(64 * EV_WPB), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
                                (float*)nullptr, frame_max, cand_count, cand, seg_cap, quality, mod, pass);
         else
-            hipLaunchKernelGGL((k_gftt_eig<false, false>), grid, dim3(256), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+            hipLaunchKernelGGL((k_gftt_eig<false, false>), grid, dim3(64 * EV_WPB), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
                                (float*)nullptr, frame_max, cand_count, cand, seg_cap, quality, mod, pass);
     }
 }

@@ -1,19 +1,17 @@
 /* Brute-force Hamming kNN (k = 2) on 256-bit descriptors (cv::BFMatcher(NORM_HAMMING).knnMatch
  * semantics), ratio test and shard merge, for gfx950.
  *
- * Integer-VALU bound (8 xor + 8 popcount-accumulate per pair), not HBM bound: each lane keeps
- * one query descriptor in 8 VGPRs; the train descriptors of a chunk are wave-uniform, so they
- * are fetched once per wave through the scalar data path and broadcast to all 64 lanes as
- * SGPR operands.  A workgroup covers 256 queries x one train chunk; per-chunk top-2 lists are
- * merged by (distance, index), which reproduces the order of one ascending scan with strict
- * '<' (ties keep the lower train index).
+ * Arithmetic bound, not HBM bound: every train row (32 bytes) meets every query, i.e. thousands of
+ * 256-bit comparisons per byte fetched.  The comparisons run on the matrix cores as products of +-1
+ * vectors (see below); a workgroup covers up to 2048 queries x one chunk of train rows, and per-chunk
+ * top-2 lists are merged by (distance, index), which reproduces the order of one ascending scan with
+ * strict '<' (ties keep the lower train index).
  */
 #include "vfe_common.h"
 #include <mutex>
 
 typedef unsigned int u32;
 
-#define MT_THREADS 256
 #define NO_IDX (-1)
 #define NO_DIST 0x7fffffff
 
@@ -23,68 +21,228 @@ __device__ static inline void top2_insert(int d, int i, int& d0, int& i0, int& d
     else if (d < d1 || (d == d1 && i < i1)) { d1 = d; i1 = i; }
 }
 
-/* Top-2 of the train rows [0, n) at `tr` (n <= 65536, wave-uniform address: scalar loads) for the query in a[]: the
- * running pair is kept as two keys dist << 16 | row, so that the lexicographic (dist, row) order -- the order of one
- * ascending scan with strict '<' -- is the integer order and an update is a median and a minimum. */
-#define KEY_NONE 0x7fffffffu
-#define SCAN_MAX_ROWS 65536
-struct Row8 { u32 w[8]; };
-/* d + popcount(x): the accumulating form, which the compiler trades for separate counts and three-operand adds */
-__device__ static inline u32 popc_acc(u32 x, u32 d) {
-    u32 r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(d));
+/* ---- the search on the matrix cores --------------------------------------------------------------------------------
+ * With every bit b written as the number 1 - 2b, the inner product of two descriptors is 256 - 2 * hamming: the
+ * distance table of a block of train rows against a block of queries is a matrix product with K = 256, and the nearest
+ * neighbour is the largest product.  +1 and -1 are exact in the 4-bit float format, whose block-scaled MFMA
+ * (v_mfma_scale_f32_32x32x64_f8f6f4, 32 x 32 results from 64-deep operands in 32 cycles, fp32 accumulation, scales 1)
+ * delivers a 32 x 32 tile of distances in four instructions: 128 cycles where the vector ALU needs ~1300.
+ *
+ * A workgroup of eight waves serves QT x 256 queries and one chunk of train rows.  Every wave keeps the expanded
+ * descriptors of its QT x 32 queries in registers for the whole chunk (the B operand: the query is the column of the
+ * result, i.e. it sits on the lane, lanes l and l + 32 hold the rows 4h .. 4h + 3 (+8, +16, +24) of a column's
+ * results).  The train rows pass through LDS 32 at a time: all threads expand a tile of packed rows (1 KB) into
+ * nibbles (4 KB) while the previous tile is being multiplied; each wave reads the tile as its A operand.  How the 256
+ * positions are dealt to instructions and lane halves does not matter as long as both operands use the same deal:
+ * lane half h takes descriptor words 4h .. 4h + 3, instruction s the word 4h + s.
+ *
+ * Top-2 per lane: a result's key is product + (32767 - (16 * step + register)) / 32768, i.e. among equal products the
+ * row met first (the lower train index) has the larger key, and the key says which row it was; products are even
+ * integers of magnitude <= 256, so the sum is exact in fp32 (9 + 15 bits).  The running pair (k1 >= k2) is updated by
+ * k2 = med3(k1, k2, key), k1 = max(k1, key).  Most tiles cannot change any lane's pair (after t tiles a tile's chance
+ * is ~32 / t per query), so a tile first takes the maximum of its 16 raw products per lane and the update runs only
+ * if some lane's maximum exceeds its k2 (a product equal to floor(k2) belongs to a later row and loses).  Rows past
+ * the end of the chunk get a bias that keeps them below every real key. */
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define MM_WAVES 8
+#define MM_ROW_DW 36                 /* LDS row: 32 dwords of nibbles + 4 of padding (ds_read_b128 of 32 rows: no bank conflicts) */
+#define MM_TILE_DW (32 * MM_ROW_DW)
+#define MM_MAX_ROWS 65536            /* per chunk: 2048 steps x 16 rows per lane fit the 15-bit position of a key */
+#define MM_AHEAD 4                  /* train tiles requested ahead of the one being written to LDS: with few query tiles
+                                      * per wave a step is a few hundred cycles, a trip to memory thousands */
+#define MM_NONE (-1024.f)
+
+/* bits 0..7 of x -> eight 4-bit floats, bit b as 1 - 2b (0x2 = +1.0, 0xA = -1.0) */
+__device__ static inline u32 spread8(u32 x) {
+    u32 t = (x | (x << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return (t << 3) | 0x22222222u;
+}
+__device__ static inline v4i spread32(u32 w) {
+    v4i r;
+    r[0] = (int)spread8(w & 0xFFu); r[1] = (int)spread8((w >> 8) & 0xFFu);
+    r[2] = (int)spread8((w >> 16) & 0xFFu); r[3] = (int)spread8(w >> 24);
     return r;
 }
-__device__ static inline void top2_row(const u32 (&a)[8], const Row8& r, u32 t, u32& k0, u32& k1) {
-    u32 d = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) d = popc_acc(a[k] ^ r.w[k], d);
-    const u32 key = (d << 16) | t;
-    u32 m;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(k0), "v"(k1), "v"(key)); /* second smallest of the three */
-    k1 = m;
-    k0 = min(k0, key);
-}
-__device__ static inline void scan_top2(const u32 (&a)[8], const u32* __restrict__ tr, int n, u32& k0, u32& k1) {
-    k0 = k1 = KEY_NONE;
-    if (n <= 0) return;
-    /* the row after the one being compared is already on its way (the last row is requested twice) */
-    const Row8* rows = reinterpret_cast<const Row8*>(tr);
-    Row8 cur = rows[0];
-    int t = 0;
-    for (; t + 2 <= n; t += 2) {
-        const Row8 nx = rows[t + 1];
-        top2_row(a, cur, (u32)t, k0, k1);
-        cur = rows[min(t + 2, n - 1)];
-        top2_row(a, nx, (u32)t + 1u, k0, k1);
-    }
-    if (t < n) top2_row(a, cur, (u32)t, k0, k1);
-}
-__device__ static inline void key_decode(u32 key, int row0, int& d, int& i) {
-    d = key == KEY_NONE ? NO_DIST : (int)(key >> 16);
-    i = key == KEY_NONE ? NO_IDX : row0 + (int)(key & 0xFFFFu);
+/* row of a tile that result register `reg` of lane half h holds */
+__device__ static inline int mm_reg_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+/* (distance, index) of a key; `row0` = train index of the chunk's first row */
+__device__ static inline void mm_decode(float key, int h, int row0, int& d, int& i) {
+    const float p = floorf(key);
+    if (key < -512.f || ((int)p & 1)) { d = NO_DIST; i = NO_IDX; return; } /* nothing found, or a floor (see mm_scan) */
+    const int pos = 32767 - (int)((key - p) * 32768.f);
+    d = (256 - (int)p) >> 1;
+    i = row0 + (pos >> 4) * 32 + mm_reg_row(pos & 15, h);
 }
 
-__global__ __launch_bounds__(MT_THREADS) void k_match(const u32* __restrict__ query, int nq,
-                                                     const u32* __restrict__ train, long long nt, int chunk,
-                                                     int nchunks, int base_index,
-                                                     int* __restrict__ part_idx, int* __restrict__ part_dist) {
-    const int q = blockIdx.x * MT_THREADS + threadIdx.x;
-    const int c = blockIdx.y;
-    u32 a[8];
+/* Keys of the two nearest rows among tr[0 .. n_rows) for the workgroup's queries q0 + (wave * QT + j) * 32 + (lane & 31),
+ * j < QT, over the rows this lane half sees.  `lds`: 3 * MM_TILE_DW dwords.  All 512 threads take part.
+ * `floor_key` (may be NULL): per query an odd integer F = (product of a row already known to be the query's second
+ * nearest elsewhere) - 1.  The pair starts at (F, F) instead of 'nothing': rows with a smaller product cannot be among the
+ * query's two nearest, so they no longer trigger updates; rows with the same product still enter (their key exceeds F)
+ * and are ordered by index when the lists are merged.  Real keys have even integer parts, so a floor left in a pair
+ * decodes as 'nothing found'. */
+template <int QT>
+__device__ static inline void mm_scan(const u32* __restrict__ query, int nq, int q0, const u32* __restrict__ tr, int n_rows,
+                                      const float* __restrict__ floor_key, u32* lds, float (&k1)[QT], float (&k2)[QT]) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    v4i Bf[QT][4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) a[k] = (q < nq) ? query[(size_t)q * 8 + k] : 0u;
+    for (int j = 0; j < QT; j++) {
+        const int q = q0 + (wv * QT + j) * 32 + c;
+        u32 w[4] = {0u, 0u, 0u, 0u};
+        if (q < nq) __builtin_memcpy(w, query + (size_t)q * 8 + 4 * h, 16);
+#pragma unroll
+        for (int s = 0; s < 4; s++) Bf[j][s] = spread32(w[s]);
+        k1[j] = k2[j] = (floor_key && q < nq) ? floor_key[q] : MM_NONE;
+    }
+    if (n_rows <= 0) return;
+    const int n_steps = (n_rows + 31) >> 5;
+    /* staging: thread -> (row, descriptor word, half of the word) of the tile */
+    const int srow = tid >> 4, sd = (tid >> 1) & 7, shalf = tid & 1;
+    const u32 lds_w = (u32)(srow * MM_ROW_DW + 4 * sd + 2 * shalf);
+    const u32 lds_r = (u32)(c * MM_ROW_DW + 16 * h);
+    auto gload = [&](int step) -> u32 { return tr[(size_t)min(step * 32 + srow, n_rows - 1) * 8 + sd]; };
+    auto swrite = [&](u32 w, int buf) {
+        const u32 x = w >> (16 * shalf);
+        uint2 v;
+        v.x = spread8(x & 0xFFu); v.y = spread8((x >> 8) & 0xFFu);
+        *reinterpret_cast<uint2*>(lds + buf * MM_TILE_DW + lds_w) = v;
+    };
+    /* the C input of a tile's first MFMA: the position part of the keys of this step's 16 rows (rows past the end of
+     * the chunk get a value that keeps them below every real key) */
+    v16f cin;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cin[r] = (float)(32767 + 16 - r) * (1.f / 32768.f);
+    auto set_cin = [&](int step) { /* steps in ascending order */
+#pragma unroll
+        for (int r = 0; r < 16; r++) cin[r] -= 16.f / 32768.f;
+        if (step == n_steps - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (step * 32 + mm_reg_row(r, h) >= n_rows) cin[r] = -4096.f;
+        }
+    };
+    const int scale = 0x7f7f7f7f; /* E8M0 127 = 1.0 for every block */
+    auto read_tile = [&](int buf, v8i (&F)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const v4i a = *reinterpret_cast<const v4i*>(lds + buf * MM_TILE_DW + lds_r + 4 * s);
+            F[s] = v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+        }
+    };
+    v8i Af[4], An[4];
+    auto tile = [&](int j) -> v16f {
+        v16f acc = cin;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const v8i b = v8i{Bf[j][s][0], Bf[j][s][1], Bf[j][s][2], Bf[j][s][3], 0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[s], b, acc, 4, 4, 0, scale, 0, scale);
+        }
+        return acc;
+    };
+    const float big = 1e30f; /* med3(a, b, big) = max(a, b) for keys; a maximum proper would first quiet each input */
+    /* Three LDS tiles.  At the top of step s: Af holds tile s, tile s + 1 is complete in LDS, the packed rows of the
+     * tiles from s + 2 on are on their way from memory, and the products of (tile s, query tile 0) are in flight.  The step writes tile
+     * s + 2, requests a tile further on, reads tile s + 1 into registers early, and meets the other waves once, before the
+     * first product of the next step.  The products of the next query tile are always issued before the keys of the
+     * current one are looked at, so that a tile's vector work runs in the shadow of the next tile's matrix work. */
+    u32 pre[MM_AHEAD]; /* packed rows of tiles step + 2 .. step + 1 + MM_AHEAD */
+    {
+        const u32 g0 = gload(0), g1 = gload(1);
+#pragma unroll
+        for (int i = 0; i < MM_AHEAD; i++) pre[i] = gload(2 + i);
+        swrite(g0, 0);
+        swrite(g1, 1);
+    }
+    __syncthreads();
+    read_tile(0, Af);
+    set_cin(0);
+    v16f acc = tile(0);
+    int wbuf = 2, rbuf = 1; /* (step + 2) % 3, (step + 1) % 3 */
+    for (int step = 0; step < n_steps; step++) {
+        const bool more = step + 1 < n_steps; /* wave-uniform */
+        swrite(pre[0], wbuf);
+#pragma unroll
+        for (int i = 0; i + 1 < MM_AHEAD; i++) pre[i] = pre[i + 1];
+        pre[MM_AHEAD - 1] = gload(step + 2 + MM_AHEAD);
+        read_tile(rbuf, An);
+#pragma unroll
+        for (int j = 0; j < QT; j++) {
+            v16f nxt = acc;
+            if (j + 1 < QT) nxt = tile(j + 1);
+            else {
+                __syncthreads();
+                if (more) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) Af[s] = An[s];
+                    set_cin(step + 1);
+                    nxt = tile(0);
+                }
+            }
+            /* keeps the order: without it the compiler moves the matrix instructions down to where their results are
+             * read, behind this tile's vector work */
+            asm volatile("" : "+v"(nxt), "+v"(acc));
+            /* compiler-visible arithmetic on the results: it pads the wait an MFMA result needs before a vector
+             * instruction may read it, which it does not do for inline assembly */
+            float m = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) m = __builtin_fmaxf(m, acc[r]);
+            if (__builtin_amdgcn_ballot_w64(m > k2[j]) != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    k2[j] = __builtin_amdgcn_fmed3f(k1[j], k2[j], acc[r]);
+                    k1[j] = __builtin_amdgcn_fmed3f(k1[j], acc[r], big);
+                }
+            }
+            acc = nxt;
+        }
+        wbuf = wbuf == 2 ? 0 : wbuf + 1;
+        rbuf = rbuf == 2 ? 0 : rbuf + 1;
+    }
+}
+
+/* the lane's two keys of query tile j -> the query's two nearest rows (both lane halves), valid in lanes 0..31 */
+__device__ static inline void mm_finish(float k1, float k2, int h, int row0, int& d0, int& i0, int& d1, int& i1) {
+    int da, ia, db, ib;
+    mm_decode(k1, h, row0, da, ia);
+    mm_decode(k2, h, row0, db, ib);
+    d0 = da; i0 = ia; d1 = db; i1 = ib;
+    const int oda = __shfl_xor(da, 32), oia = __shfl_xor(ia, 32), odb = __shfl_xor(db, 32), oib = __shfl_xor(ib, 32);
+    if (oia >= 0) top2_insert(oda, oia, d0, i0, d1, i1);
+    if (oib >= 0) top2_insert(odb, oib, d0, i0, d1, i1);
+}
+
+/* workgroup (c, qb): chunk c of the train rows against queries qb * QT * 256 ..; the top-2 list of (query q, chunk c) goes
+ * to list slot q * list_stride + list0 + c */
+template <int QT>
+__global__ __launch_bounds__(64 * MM_WAVES) void k_match_mm(const u32* __restrict__ query, int nq,
+                                                            const u32* __restrict__ train, long long nt, int chunk,
+                                                            int list_stride, int list0, int base_index, const float* __restrict__ floor_key,
+                                                            int* __restrict__ part_idx, int* __restrict__ part_dist) {
+    __shared__ __align__(16) u32 s_tile[3 * MM_TILE_DW];
+    const int c = blockIdx.x, q0 = blockIdx.y * (QT * 32 * MM_WAVES);
     const long long t0 = (long long)c * chunk;
     const long long t1 = (t0 + chunk < nt) ? t0 + chunk : nt;
-    u32 k0, k1;
-    scan_top2(a, train + (size_t)t0 * 8, (int)(t1 - t0), k0, k1); /* chunk <= SCAN_MAX_ROWS */
-    int d0, d1, i0, i1;
-    key_decode(k0, base_index + (int)t0, d0, i0);
-    key_decode(k1, base_index + (int)t0, d1, i1);
-    if (q < nq) {
-        const size_t o = ((size_t)q * nchunks + c) * 2;
-        part_idx[o] = i0; part_idx[o + 1] = i1;
-        part_dist[o] = d0; part_dist[o + 1] = d1;
+    float k1[QT], k2[QT];
+    mm_scan<QT>(query, nq, q0, train + (size_t)t0 * 8, (int)(t1 - t0), floor_key, s_tile, k1, k2);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int j = 0; j < QT; j++) {
+        int d0, i0, d1, i1;
+        mm_finish(k1[j], k2[j], lane >> 5, base_index + (int)t0, d0, i0, d1, i1);
+        const int q = q0 + (wv * QT + j) * 32 + lane;
+        if (lane < 32 && q < nq) {
+            const size_t o = ((size_t)q * list_stride + list0 + c) * 2;
+            part_idx[o] = i0; part_idx[o + 1] = i1;
+            part_dist[o] = d0; part_dist[o + 1] = d1;
+        }
     }
 }
 
@@ -112,7 +270,8 @@ __global__ __launch_bounds__(256) void k_merge(const int* __restrict__ in_idx, c
  * top-2 lists are merged by a butterfly.  The two smallest (dist, idx) pairs of a set do not depend on the order in
  * which its members are visited, so the result is the one of the serial merge. */
 __global__ __launch_bounds__(256) void k_merge_wave(const int* __restrict__ in_idx, const int* __restrict__ in_dist,
-                                                    int nlists, int nq, int* __restrict__ out_idx, int* __restrict__ out_dist) {
+                                                    int nlists, int nq, int* __restrict__ out_idx, int* __restrict__ out_dist,
+                                                    int out_stride, float* __restrict__ floor_key) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (q >= nq) return;
@@ -130,9 +289,11 @@ __global__ __launch_bounds__(256) void k_merge_wave(const int* __restrict__ in_i
         if (pi0 >= 0) top2_insert(pd0, pi0, d0, i0, d1, i1);
         if (pi1 >= 0) top2_insert(pd1, pi1, d0, i0, d1, i1);
     }
-    if (lane == 0) {
-        out_idx[2 * q] = i0; out_idx[2 * q + 1] = i1;
-        out_dist[2 * q] = d0; out_dist[2 * q + 1] = d1;
+    if (lane == 0) { /* the result is list slot q * out_stride; out_stride = 1: the final [nq][2] layout */
+        const size_t o = (size_t)q * out_stride * 2;
+        out_idx[o] = i0; out_idx[o + 1] = i1;
+        out_dist[o] = d0; out_dist[o + 1] = d1;
+        if (floor_key) floor_key[q] = i1 >= 0 ? (float)(256 - 2 * d1 - 1) : MM_NONE; /* see mm_scan */
     }
 }
 
@@ -143,110 +304,176 @@ __global__ __launch_bounds__(256) void k_ratio(const int* __restrict__ idx, cons
     good[q] = (idx[2 * q] >= 0 && idx[2 * q + 1] >= 0 && (float)dist[2 * q] < ratio * (float)dist[2 * q + 1]) ? 1 : 0;
 }
 
-/* Batched frame-to-frame matching: workgroup (x, b) serves 64 queries of frame b; its MB_WAVES waves scan
- * an equal share of that frame's train rows each and merge their top-2 lists through LDS (eight waves: 16 frame pairs of
- * 2000 descriptors are then 4096 waves, four per SIMD, instead of two).  Set sizes come
- * from device memory, so extraction and matching can be queued back to back. */
-#define MB_WAVES 8
-__global__ __launch_bounds__(64 * MB_WAVES) void k_match_batch(const u32* __restrict__ query, const int* __restrict__ nq_dev, int q_cap,
-                                                     const u32* __restrict__ train, const int* __restrict__ nt_dev, int t_cap,
-                                                     int* __restrict__ out_idx, int* __restrict__ out_dist, float ratio,
-                                                     uint8_t* __restrict__ good) {
-    __shared__ int s_i[MB_WAVES][64][2], s_d[MB_WAVES][64][2];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nq = min(max(nq_dev[b], 0), q_cap), nt = min(max(nt_dev[b], 0), t_cap);
-    const int q = blockIdx.x * 64 + lane;
-    const u32* qp = query + ((size_t)b * q_cap + min(q, q_cap - 1)) * 8;
-    u32 a[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) a[k] = qp[k];
+/* Batched frame-to-frame matching: workgroup (x, b) serves QT * 256 queries of frame b against all of that frame's train
+ * rows, so its lists are final and the ratio test can follow at once.  Set sizes come from device memory, so extraction
+ * and matching can be queued back to back. */
+template <int QT>
+__global__ __launch_bounds__(64 * MM_WAVES) void k_match_mm_batch(const u32* __restrict__ query, const int* __restrict__ nq_dev, int q_cap,
+                                                                  const u32* __restrict__ train, const int* __restrict__ nt_dev, int t_cap,
+                                                                  int* __restrict__ out_idx, int* __restrict__ out_dist, float ratio,
+                                                                  uint8_t* __restrict__ good) {
+    __shared__ __align__(16) u32 s_tile[3 * MM_TILE_DW];
+    const int b = blockIdx.y, q0 = blockIdx.x * (QT * 32 * MM_WAVES);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nq = min(max(nq_dev[b], 0), q_cap);
     /* workgroups past the last query only write the 'no neighbour' records */
-    const int per = (nt + MB_WAVES - 1) / MB_WAVES, t0 = min(wv * per, nt), t1 = (int)blockIdx.x * 64 < nq ? min(t0 + per, nt) : t0;
+    const int nt = q0 < nq ? min(max(nt_dev[b], 0), t_cap) : 0;
+    const u32* qb = query + (size_t)b * q_cap * 8;
     const u32* tb = train + (size_t)b * t_cap * 8;
-    int d0 = NO_DIST, d1 = NO_DIST, i0 = NO_IDX, i1 = NO_IDX;
-    for (int ts = t0; ts < t1; ts += SCAN_MAX_ROWS) { /* one round unless the set is huge */
-        u32 k0, k1;
-        scan_top2(a, tb + (size_t)ts * 8, min(t1 - ts, SCAN_MAX_ROWS), k0, k1);
-        int d, i;
-        key_decode(k0, ts, d, i);
-        if (i >= 0) top2_insert(d, i, d0, i0, d1, i1);
-        key_decode(k1, ts, d, i);
-        if (i >= 0) top2_insert(d, i, d0, i0, d1, i1);
+    int d0[QT], i0[QT], d1[QT], i1[QT];
+#pragma unroll
+    for (int j = 0; j < QT; j++) { d0[j] = d1[j] = NO_DIST; i0[j] = i1[j] = NO_IDX; }
+    for (int ts = 0; ts < nt; ts += MM_MAX_ROWS) { /* one round unless the set is huge */
+        float k1[QT], k2[QT];
+        mm_scan<QT>(qb, nq, q0, tb + (size_t)ts * 8, min(nt - ts, MM_MAX_ROWS), nullptr, s_tile, k1, k2);
+        __syncthreads(); /* the next round reuses the tiles */
+#pragma unroll
+        for (int j = 0; j < QT; j++) {
+            int da, ia, db, ib;
+            mm_finish(k1[j], k2[j], lane >> 5, ts, da, ia, db, ib);
+            if (ia >= 0) top2_insert(da, ia, d0[j], i0[j], d1[j], i1[j]);
+            if (ib >= 0) top2_insert(db, ib, d0[j], i0[j], d1[j], i1[j]);
+        }
     }
-    s_i[wv][lane][0] = i0; s_i[wv][lane][1] = i1; s_d[wv][lane][0] = d0; s_d[wv][lane][1] = d1;
-    __syncthreads();
-    if (wv == 0 && q < q_cap) {
-        d0 = d1 = NO_DIST; i0 = i1 = NO_IDX;
 #pragma unroll
-        for (int w = 0; w < MB_WAVES; w++)
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-                if (s_i[w][lane][k] >= 0) top2_insert(s_d[w][lane][k], s_i[w][lane][k], d0, i0, d1, i1);
-        if (q >= nq) { d0 = d1 = NO_DIST; i0 = i1 = NO_IDX; }
-        const size_t o = ((size_t)b * q_cap + q) * 2;
-        out_idx[o] = i0; out_idx[o + 1] = i1;
-        out_dist[o] = d0; out_dist[o + 1] = d1;
-        if (good) good[(size_t)b * q_cap + q] = (i0 >= 0 && i1 >= 0 && (float)d0 < ratio * (float)d1) ? 1 : 0;
+    for (int j = 0; j < QT; j++) {
+        const int q = q0 + (wv * QT + j) * 32 + lane;
+        if (lane < 32 && q < q_cap) {
+            if (q >= nq) { d0[j] = d1[j] = NO_DIST; i0[j] = i1[j] = NO_IDX; }
+            const size_t o = ((size_t)b * q_cap + q) * 2;
+            out_idx[o] = i0[j]; out_idx[o + 1] = i1[j];
+            out_dist[o] = d0[j]; out_dist[o + 1] = d1[j];
+            if (good) good[(size_t)b * q_cap + q] = (i0[j] >= 0 && i1[j] >= 0 && (float)d0[j] < ratio * (float)d1[j]) ? 1 : 0;
+        }
     }
 }
 
-static int match_chunk(int nq, long long nt) {
-    /* enough (query block x chunk) workgroups to fill 256 CUs several times, chunks >= 64 rows */
-    const long long qblocks = (nq + MT_THREADS - 1) / MT_THREADS;
-    long long want = 4096 / (qblocks > 0 ? qblocks : 1);
+/* Query tiles per wave (a workgroup serves QT * 256 queries) and rows per chunk: one workgroup per CU and round where the
+ * train set allows it -- long chunks keep the top-2 update rare -- chunks of whole 32-row tiles, at least 256 rows. */
+struct MatchGeom {
+    int qt, chunk; long long nchunks; unsigned qblocks;
+    /* large train sets: a sample of the first s_rows rows (s_chunks chunks of s_chunk rows) is searched first; its
+     * second-nearest distance per query becomes the floor of the main search over the rest (mm_scan) */
+    int s_chunk, s_chunks; long long s_rows;
+    long long lists; /* top-2 lists per query that the final merge reads */
+};
+#define MM_SAMPLE_CHUNK 128          /* rows per sample chunk */
+#define MM_SAMPLE_MIN_ROWS 500000    /* train sets from this size on are searched with a floor */
+static MatchGeom match_geom(int nq, long long nt) {
+    MatchGeom g;
+    g.qt = nq > 1024 ? 8 : nq > 512 ? 4 : nq > 256 ? 2 : 1;
+    g.qblocks = (unsigned)((nq + g.qt * 256 - 1) / (g.qt * 256));
+    long long want = 256 / (long long)g.qblocks;
     if (want < 1) want = 1;
-    long long chunk = (nt + want - 1) / want;
-    if (chunk < 64) chunk = 64;
-    if (chunk > 65536) chunk = 65536;
-    return (int)chunk;
+    g.s_chunk = MM_SAMPLE_CHUNK; g.s_chunks = 0; g.s_rows = 0;
+    if (nt >= MM_SAMPLE_MIN_ROWS) { g.s_chunks = (int)want; g.s_rows = (long long)g.s_chunks * g.s_chunk; }
+    const long long rest = nt - g.s_rows;
+    long long chunk = ((rest + want - 1) / want + 31) / 32 * 32;
+    if (chunk < 256) chunk = 256;
+    if (chunk > MM_MAX_ROWS) chunk = MM_MAX_ROWS;
+    g.chunk = (int)chunk;
+    g.nchunks = rest > 0 ? (rest + chunk - 1) / chunk : 1;
+    g.lists = g.nchunks + (g.s_chunks ? 1 : 0);
+    return g;
+}
+
+/* workspace: the lists the final merge reads, then (with a sample) the sample's lists and the floors */
+struct MatchWs { size_t idx, dist, s_idx, s_dist, floor, total; };
+static MatchWs match_ws(int nq, const MatchGeom& g) {
+    MatchWs w;
+    size_t o = 0;
+    const size_t lists = align_up((size_t)nq * g.lists * 2 * sizeof(int), 256);
+    const size_t s_lists = align_up((size_t)nq * g.s_chunks * 2 * sizeof(int), 256);
+    w.idx = o; o += lists;
+    w.dist = o; o += lists;
+    w.s_idx = o; o += s_lists;
+    w.s_dist = o; o += s_lists;
+    w.floor = o; o += g.s_chunks ? align_up((size_t)nq * sizeof(float), 256) : 0;
+    w.total = o;
+    return w;
 }
 
 extern "C" size_t vfe_match_workspace(int nq, long long nt) {
     if (nq <= 0 || nt < 0) return 0;
-    const int chunk = match_chunk(nq, nt);
-    const long long nchunks = nt > 0 ? (nt + chunk - 1) / chunk : 1;
-    return align_up((size_t)nq * nchunks * 2 * sizeof(int), 256) * 2;
+    return match_ws(nq, match_geom(nq, nt)).total;
 }
 
-/* k_match over all (query block, chunk) pairs into the partial lists at `workspace` (vfe_match_workspace bytes), then
- * the merge of every query's lists */
+static void match_merge(const int* in_idx, const int* in_dist, long long nlists, int nq, int* out_idx, int* out_dist,
+                        int out_stride, float* floor_key, hipStream_t st) {
+    if (nlists >= 16 || out_stride != 1 || floor_key) /* a thread per query would walk its lists alone: a wave per query instead */
+        hipLaunchKernelGGL(k_merge_wave, dim3((nq + 3) / 4), dim3(256), 0, st, in_idx, in_dist, (int)nlists, nq, out_idx, out_dist,
+                           out_stride, floor_key);
+    else
+        hipLaunchKernelGGL(k_merge, dim3((nq + 255) / 256), dim3(256), 0, st, in_idx, in_dist, (int)nlists,
+                           (size_t)nlists, (size_t)1, nq, out_idx, out_dist);
+}
+
+/* k_match_mm over all (chunk, query block) pairs into the lists at `workspace` (vfe_match_workspace bytes), then the merge
+ * of every query's lists; with a sample, the same two steps over the sample first */
 static int match_launch(const uint8_t* query, int nq, const uint8_t* train, long long nt, int base_index,
-                        int* out_idx, int* out_dist, void* workspace, size_t need, int chunk, long long nchunks, hipStream_t st) {
-    int* part_idx = (int*)workspace;
-    int* part_dist = (int*)((char*)workspace + need / 2);
+                        int* out_idx, int* out_dist, void* workspace, const MatchGeom& g, hipStream_t st) {
+    const MatchWs w = match_ws(nq, g);
+    char* ws = (char*)workspace;
+    int* part_idx = (int*)(ws + w.idx);
+    int* part_dist = (int*)(ws + w.dist);
+    const dim3 block(64 * MM_WAVES);
+#define MM_LAUNCH(QT, GRID, TRAIN, NT, CHUNK, STRIDE, LIST0, BASE, FLOOR, IDX, DIST)                                     \
+    hipLaunchKernelGGL(k_match_mm<QT>, GRID, block, 0, st, (const u32*)query, nq, (const u32*)(TRAIN), NT, CHUNK,       \
+                       STRIDE, LIST0, BASE, FLOOR, IDX, DIST)
+#define MM_LAUNCH_QT(...)                                                                                                \
+    switch (g.qt) {                                                                                                      \
+        case 8: MM_LAUNCH(8, __VA_ARGS__); break;                                                                        \
+        case 4: MM_LAUNCH(4, __VA_ARGS__); break;                                                                        \
+        case 2: MM_LAUNCH(2, __VA_ARGS__); break;                                                                        \
+        default: MM_LAUNCH(1, __VA_ARGS__); break;                                                                       \
+    }
+    float* floor_key = nullptr;
+    if (g.s_chunks) {
+        int* s_idx = (int*)(ws + w.s_idx);
+        int* s_dist = (int*)(ws + w.s_dist);
+        floor_key = (float*)(ws + w.floor);
+        {
+            ProfScope prof(VFE_K_MATCH, st);
+            const dim3 grid((unsigned)g.s_chunks, g.qblocks);
+            MM_LAUNCH_QT(grid, train, g.s_rows, g.s_chunk, g.s_chunks, 0, base_index, (const float*)nullptr, s_idx, s_dist);
+        }
+        VFE_LAUNCH_CHECK();
+        ProfScope prof(VFE_K_MISC, st);
+        /* the sample's result is list 0 of every query */
+        match_merge(s_idx, s_dist, g.s_chunks, nq, part_idx, part_dist, (int)g.lists, floor_key, st);
+        VFE_LAUNCH_CHECK();
+    }
     {
         ProfScope prof(VFE_K_MATCH, st);
-        hipLaunchKernelGGL(k_match, dim3((nq + MT_THREADS - 1) / MT_THREADS, (unsigned)nchunks), dim3(MT_THREADS), 0, st,
-                           (const u32*)query, nq, (const u32*)train, nt, chunk, (int)nchunks, base_index, part_idx, part_dist);
+        const dim3 grid((unsigned)g.nchunks, g.qblocks);
+        MM_LAUNCH_QT(grid, train + (size_t)g.s_rows * 32, nt - g.s_rows, g.chunk, (int)g.lists, g.s_chunks ? 1 : 0,
+                     base_index + (int)g.s_rows, (const float*)floor_key, part_idx, part_dist);
     }
+#undef MM_LAUNCH_QT
+#undef MM_LAUNCH
     VFE_LAUNCH_CHECK();
     ProfScope prof(VFE_K_MISC, st);
-    if (nchunks >= 16) /* a thread per query would walk its lists alone: a wave per query instead */
-        hipLaunchKernelGGL(k_merge_wave, dim3((nq + 3) / 4), dim3(256), 0, st, part_idx, part_dist, (int)nchunks, nq, out_idx, out_dist);
-    else
-        hipLaunchKernelGGL(k_merge, dim3((nq + 255) / 256), dim3(256), 0, st, part_idx, part_dist, (int)nchunks,
-                           (size_t)nchunks, (size_t)1, nq, out_idx, out_dist);
+    match_merge(part_idx, part_dist, g.lists, nq, out_idx, out_dist, 1, nullptr, st);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
 
 static int match_check_args(const uint8_t* query, int nq, const uint8_t* train, long long nt, int base_index,
-                            const int* out_idx, const int* out_dist, int* chunk, long long* nchunks) {
+                            const int* out_idx, const int* out_dist, MatchGeom* g) {
     VFE_REQUIRE(query && out_idx && out_dist && nq > 0, "NULL buffer or nq <= 0");
     VFE_REQUIRE(nt >= 0 && (nt == 0 || train), "bad train set");
     VFE_REQUIRE((long long)base_index + nt <= 0x7fffffffLL, "train indices overflow int");
     VFE_REQUIRE((uintptr_t)query % 4 == 0 && (uintptr_t)train % 4 == 0, "descriptors must be 4-byte aligned");
-    *chunk = match_chunk(nq, nt);
-    *nchunks = nt > 0 ? (nt + *chunk - 1) / *chunk : 1;
-    VFE_REQUIRE(*nchunks <= 65535, "train set too large for one call");
+    *g = match_geom(nq, nt);
+    VFE_REQUIRE(g->lists <= 0x7fffffffLL && g->qblocks <= 65535u, "train or query set too large for one call");
     return VFE_OK;
 }
 
 extern "C" int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long long nt,
                                   int base_index, int* out_idx, int* out_dist,
                                   void* workspace, size_t workspace_bytes, void* stream) {
-    int chunk; long long nchunks;
-    const int rc = match_check_args(query, nq, train, nt, base_index, out_idx, out_dist, &chunk, &nchunks);
+    MatchGeom g;
+    const int rc = match_check_args(query, nq, train, nt, base_index, out_idx, out_dist, &g);
     if (rc != VFE_OK) return rc;
     const size_t need = vfe_match_workspace(nq, nt);
     if (!workspace || workspace_bytes < need) {
@@ -254,7 +481,7 @@ extern "C" int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* t
         return VFE_E_NOMEM;
     }
     VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
-    return match_launch(query, nq, train, nt, base_index, out_idx, out_dist, workspace, need, chunk, nchunks, (hipStream_t)stream);
+    return match_launch(query, nq, train, nt, base_index, out_idx, out_dist, workspace, g, (hipStream_t)stream);
 }
 
 /* ---- the same search for callers that cannot allocate --------------------------------------------------------------
@@ -262,7 +489,7 @@ extern "C" int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* t
  * runs on holds its own copy of the array at its own address for the life of the process; the host-side name below is
  * only a handle for hipGetSymbolAddress, never a device address, so every use goes through the per-device pointer
  * resolved once (vfe_match_scratch_init, called by vfe_create and by the entry point's first call on a device).
- * k_match writes every (query, chunk) slot the merge reads, so nothing has to be cleared between calls; calls that
+ * The search kernels write every list slot and floor the merges read, so nothing has to be cleared between calls; calls that
  * overlap on one GPU share the array and race. */
 static __device__ __align__(256) unsigned char scratch[VFE_MATCH_NOALLOC_BYTES];
 #define MATCH_MAX_DEVICES 64
@@ -286,19 +513,19 @@ int vfe_match_scratch_init(void** out) {
 
 extern "C" int vfe_dev_match_knn2_noalloc(const uint8_t* query, int nq, const uint8_t* train, long long nt,
                                           int base_index, int* out_idx, int* out_dist, void* stream) {
-    int chunk; long long nchunks;
-    int rc = match_check_args(query, nq, train, nt, base_index, out_idx, out_dist, &chunk, &nchunks);
+    MatchGeom g;
+    int rc = match_check_args(query, nq, train, nt, base_index, out_idx, out_dist, &g);
     if (rc != VFE_OK) return rc;
     const size_t need = vfe_match_workspace(nq, nt);
     if (need > (size_t)VFE_MATCH_NOALLOC_BYTES) {
         vfe_set_error("%d queries x %lld chunks need %zu bytes of partial lists, the built-in scratch holds %zu: "
-                      "use vfe_dev_match_knn2 with a workspace", nq, nchunks, need, (size_t)VFE_MATCH_NOALLOC_BYTES);
+                      "use vfe_dev_match_knn2 with a workspace", nq, g.lists, need, (size_t)VFE_MATCH_NOALLOC_BYTES);
         return VFE_E_CAPACITY;
     }
     void* ws = nullptr;
     rc = vfe_match_scratch_init(&ws);
     if (rc != VFE_OK) return rc;
-    return match_launch(query, nq, train, nt, base_index, out_idx, out_dist, ws, need, chunk, nchunks, (hipStream_t)stream);
+    return match_launch(query, nq, train, nt, base_index, out_idx, out_dist, ws, g, (hipStream_t)stream);
 }
 
 extern "C" int vfe_dev_merge_knn2(const int* shard_idx, const int* shard_dist, int nshards, int nq,
@@ -326,8 +553,20 @@ extern "C" int vfe_dev_match_knn2_batch(const uint8_t* query, const int* nq, int
     VFE_REQUIRE(q_cap > 0 && t_cap > 0 && batch > 0 && batch <= 65535, "bad sizes");
     VFE_REQUIRE((uintptr_t)query % 4 == 0 && (uintptr_t)train % 4 == 0, "descriptors must be 4-byte aligned");
     ProfScope prof(VFE_K_MATCH, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_match_batch, dim3((q_cap + 63) / 64, batch), dim3(64 * MB_WAVES), 0, (hipStream_t)stream,
-                       (const u32*)query, nq, q_cap, (const u32*)train, nt, t_cap, out_idx, out_dist, ratio, good);
+    /* the most query tiles per wave that still give every CU a workgroup */
+    int qt = 8;
+    while (qt > 1 && (long long)((q_cap + qt * 256 - 1) / (qt * 256)) * batch < 256) qt >>= 1;
+    const dim3 grid((unsigned)((q_cap + qt * 256 - 1) / (qt * 256)), (unsigned)batch), block(64 * MM_WAVES);
+#define MM_LAUNCH(QT)                                                                                                  \
+    hipLaunchKernelGGL(k_match_mm_batch<QT>, grid, block, 0, (hipStream_t)stream, (const u32*)query, nq, q_cap,        \
+                       (const u32*)train, nt, t_cap, out_idx, out_dist, ratio, good)
+    switch (qt) {
+        case 8: MM_LAUNCH(8); break;
+        case 4: MM_LAUNCH(4); break;
+        case 2: MM_LAUNCH(2); break;
+        default: MM_LAUNCH(1); break;
+    }
+#undef MM_LAUNCH
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
