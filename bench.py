@@ -417,13 +417,12 @@ def run_orb_match_leg(rk, frames, batch, steps, warmup, counters):
     good = float(state["out"][2].float().sum(dim=1).mean().item())
     per_frame = {"k_orb_resize": px[0] + sum(px[1:]),           # read level 0, write levels 1..7
                  "k_fast": sum(px) + 12 * nk,                    # read every level once, write (x, y, score) per keypoint
-                 "k_orb_blur": 2 * sum(px),                      # read + write every level
                  "k_orb_select": 12 * nk + 32 * nk,              # FAST keypoints in, keypoint records out
-                 "k_orb_desc": 32 * nk + 32 * nk,                # keypoint records in, descriptors out (patch reads hit the blurred pyramid)
+                 "k_orb_desc": (32 + 43 * 48 + 32) * nk,         # keypoint records and 43 x 48 level windows in, descriptors out
                  "k_match": 32 * (2 * nk) + 16 * nk + nk}        # both descriptor sets in, top-2 lists + flags out
     kernels = kernel_table(prof, elapsed, {k: v * batch for k, v in per_frame.items()}, steps)
     total = rk.sum_over_ranks(batch * steps)
-    orb_bytes = px[0] + sum(px[1:]) + 2 * sum(px) + 64 * nk      # image in, pyramid out, blurred pyramid in + out, keypoints + descriptors out
+    orb_bytes = px[0] + sum(px[1:]) + (43 * 48 + 64) * nk        # image in, pyramid out, keypoint windows in, keypoints + descriptors out
     return {"workload": f"configs[2]: 8-level ORB ({ORB_NFEAT} keypoints, 1.2/8/31/20) on 1920x1080 frames + frame-to-frame "
                         f"Hamming kNN-2 with ratio {KNN_RATIO}, {batch} streams per GPU per step",
             "value": total / elapsed, "unit": "frames/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,

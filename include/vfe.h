@@ -273,7 +273,7 @@ int vfe_dev_frontend_step_fast(const vfe_dimg* prev_levels, const vfe_dimg* next
 
 /* ---- kernel timing (HIP events recorded around every kernel the library launches) ------- */
 enum { VFE_K_PYR_DOWN = 0, VFE_K_GFTT_EIG, VFE_K_GFTT_SELECT, VFE_K_KLT, VFE_K_COMPACT, VFE_K_APPEND,
-       VFE_K_FAST, VFE_K_ORB_RESIZE, VFE_K_ORB_BLUR, VFE_K_ORB_SELECT, VFE_K_ORB_DESC, VFE_K_MATCH,
+       VFE_K_FAST, VFE_K_ORB_RESIZE, VFE_K_ORB_SELECT, VFE_K_ORB_DESC, VFE_K_MATCH,
        VFE_K_MISC, VFE_K_COUNT };
 /* enable != 0: from now on every launch is bracketed by events on its stream. */
 int vfe_prof_enable(int enable);

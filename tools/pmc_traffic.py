@@ -21,14 +21,13 @@ SLOTS = {
     "k_append": ("k_append", ["k_append"]),
     "k_fast": ("k_fast_queue", ["k_fast_queue", "k_fast_scan_stream", "k_fast_scatter_stream"]),
     "k_orb_resize": ("k_orb_tables", ["k_orb_tables", "k_orb_resize_rows", "k_orb_resize"]),
-    "k_orb_blur": ("k_orb_blur", ["k_orb_blur"]),
     "k_orb_select": ("k_orb_hist", ["k_orb_hist", "k_orb_harris", "k_orb_thresh", "k_orb_emit"]),
     "k_orb_desc": ("k_orb_desc", ["k_orb_desc"]),
     "k_match": (None, ["k_match_mm", "k_match_mm_batch"]),  # one of the two per leg, one dispatch per scope
 }
 LEG_SLOTS = {"main": ["k_pyr_down", "k_gftt_eig", "k_gftt_select", "k_klt", "k_compact", "k_append"],
              "streams64": ["k_pyr_down", "k_gftt_eig", "k_gftt_select", "k_klt", "k_compact", "k_append"],
-             "orb_match": ["k_fast", "k_orb_resize", "k_orb_blur", "k_orb_select", "k_orb_desc", "k_match"],
+             "orb_match": ["k_fast", "k_orb_resize", "k_orb_select", "k_orb_desc", "k_match"],
              "reloc": ["k_match"]}
 
 

@@ -422,10 +422,19 @@ def prof_enable(on=True):
     check(lib().vfe_prof_enable(1 if on else 0))
 
 
+def prof_slots():
+    """Number of kernel-timing slots (vfe_prof_kernel_name answers "?" past the last one)."""
+    L = lib()
+    n = 0
+    while n < 64 and L.vfe_prof_kernel_name(n) != b"?":
+        n += 1
+    return n
+
+
 def prof_read(reset=True):
     """{kernel name: (total ms, launches)} for every kernel launched since the last reset."""
     L = lib()
-    n = 13
+    n = prof_slots()
     ms = (C.c_double * n)()
     cnt = (C.c_longlong * n)()
     check(L.vfe_prof_read(ms, cnt, 1 if reset else 0))

@@ -123,7 +123,7 @@ extern "C" int vfe_prof_read(double* ms, long long* launches, int reset) {
 
 extern "C" const char* vfe_prof_kernel_name(int id) {
     static const char* names[VFE_K_COUNT] = {"k_pyr_down", "k_gftt_eig", "k_gftt_select", "k_klt", "k_compact",
-                                             "k_append", "k_fast", "k_orb_resize", "k_orb_blur", "k_orb_select",
+                                             "k_append", "k_fast", "k_orb_resize", "k_orb_select",
                                              "k_orb_desc", "k_match", "misc"};
     return (id >= 0 && id < VFE_K_COUNT) ? names[id] : "?";
 }

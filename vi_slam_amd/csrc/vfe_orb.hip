@@ -199,13 +199,10 @@ __global__ __launch_bounds__(256) void k_orb_resize_rows(DImg src, DImg dst, con
     }
 }
 
-/* 7x7 Gaussian, sigma 2 (vfe_orb_blur.hip) */
-int orb_blur_launch(const DImg* src, const DImg* dst, int n, hipStream_t st);
 
 /* ---- keypoint selection --------------------------------------------------------------------- */
 struct OrbLevels {
     DImg raw[ORB_MAX_LEVELS];
-    DImg blur[ORB_MAX_LEVELS];
     float scale[ORB_MAX_LEVELS];
     int quota[ORB_MAX_LEVELS];
     int cap[ORB_MAX_LEVELS];          /* FAST keypoint capacity of the level */
@@ -504,11 +501,26 @@ __device__ static inline void sincos_det(float xf, float* s_out, float* c_out) {
     *s_out = (float)s; *c_out = (float)c;
 }
 
+#define DP_R 18                /* largest |coordinate| of a rotated pattern point */
+#define DP_ROWS (2 * DP_R + 7) /* rows of horizontal sums a keypoint needs */
+#define DP_W 40                /* columns of horizontal sums kept: 2 * DP_R + 1, rounded up to whole lanes of four */
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ static inline u16x2 as_h2(u32 v) { return __builtin_bit_cast(u16x2, v); }
+__device__ static inline u32 as_u(u16x2 v) { return __builtin_bit_cast(u32, v); }
+/* (byte i of the 8 bytes {hi:lo}) | (byte j) << 16 */
+__device__ static inline u32 byte_pair(u32 lo, u32 hi, int i, int j) {
+    return __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (u32)i | ((u32)j << 16));
+}
+
 __global__ __launch_bounds__(256) void k_orb_desc(OrbLevels L, vfe_orb_kp* __restrict__ kps, uint8_t* __restrict__ desc,
                                                   const int* __restrict__ counts, int out_cap, int batch) {
+    __shared__ __align__(16) unsigned short s_h[4][DP_ROWS][DP_W]; /* horizontal blur sums of the keypoint's window */
+    __shared__ __align__(16) u32 s_raw[4][DP_ROWS][DP_W / 4];       /* the window itself */
     const int lane = threadIdx.x & 63;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), nwaves = (gridDim.x * 256u) >> 6;
     const unsigned total = (unsigned)batch * (unsigned)out_cap;
+    unsigned short* hs = s_h[threadIdx.x >> 6][0];
+    u32* raw = s_raw[threadIdx.x >> 6][0];
     for (unsigned w = wave; w < total; w += nwaves) {
         const int b = w / (unsigned)out_cap, i = w - (unsigned)b * (unsigned)out_cap;
         if (i >= counts[b]) continue;
@@ -516,47 +528,90 @@ __global__ __launch_bounds__(256) void k_orb_desc(OrbLevels L, vfe_orb_kp* __res
         const int l = kp->octave, px = kp->lx, py = kp->ly;
         const DImg& I = L.raw[l];
         const uint8_t* ip = I.frame(b);
+        /* the centre of the sampling pattern is recomputed from the scaled position (equal to (px, py) up to rounding) */
+        const float sf = L.scale[l];
+        const float inv = 1.f / sf;
+        const int cx = __float2int_rn(kp->x * inv), cy = __float2int_rn(kp->y * inv);
+        /* Everything a keypoint reads lies in a 43-row x 48-column window of its level around the centre, inside the
+         * image because keypoints keep 31 pixels from the rim: the 31 x 31 patch of the intensity centroid, and the
+         * pixels under the 7x7 Gaussian (cv::GaussianBlur, sigma 2: 8.8 fixed-point taps 18 34 48 56 48 34 18, horizontal
+         * sums kept in 16 bits, one rounding after the vertical pass) at the rotated pattern points, which stay within
+         * 18 pixels of the centre (|(-13, -13)| = 18.4).  The wave loads the window once (lane -> four columns of a row
+         * as three unaligned dwords), keeps it and its horizontal blur sums in LDS, and finishes the blur only at the
+         * 512 sampled points. */
+        {
+            const uint8_t* rp = ip + (size_t)(cy - DP_R - 3) * I.pitch + (cx - DP_R);
+            constexpr int N_IT = (DP_ROWS * (DP_W / 4) + 63) / 64;
+            u32 lw[N_IT], cw[N_IT], rw[N_IT];
+#pragma unroll
+            for (int it = 0; it < N_IT; it++) { /* all loads first */
+                const int item = min(it * 64 + lane, DP_ROWS * (DP_W / 4) - 1);
+                const int r = item / (DP_W / 4), g = item - r * (DP_W / 4);
+                const uint8_t* p = rp + (size_t)r * I.pitch + 4 * g;
+                __builtin_memcpy(&lw[it], p - 4, 4); __builtin_memcpy(&cw[it], p, 4); __builtin_memcpy(&rw[it], p + 4, 4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the previous keypoint's LDS reads are done */
+#pragma unroll
+            for (int it = 0; it < N_IT; it++) {
+                const int item = it * 64 + lane;
+                /* bytes of columns x-3 .. x+6 are l1 l2 l3 c0 c1 c2 c3 r0 r1 r2 =: q0 .. q9; pixel k taps q[k] .. q[k+6] */
+                const u32 l_ = lw[it], c_ = cw[it], r_ = rw[it];
+                u16x2 P[9];
+                P[0] = as_h2(byte_pair(l_, l_, 1, 2)); P[1] = as_h2(byte_pair(l_, l_, 2, 3)); P[2] = as_h2(byte_pair(l_, c_, 3, 4));
+                P[3] = as_h2(byte_pair(c_, c_, 0, 1)); P[4] = as_h2(byte_pair(c_, c_, 1, 2)); P[5] = as_h2(byte_pair(c_, c_, 2, 3));
+                P[6] = as_h2(byte_pair(c_, r_, 3, 4)); P[7] = as_h2(byte_pair(r_, r_, 0, 1)); P[8] = as_h2(byte_pair(r_, r_, 1, 2));
+                uint2 h;
+                /* 18 (q0+q6) + 34 (q1+q5) + 48 (q2+q4) + 56 q3 <= 65280: fits 16 bits */
+                h.x = as_u((P[0] + P[6]) * (unsigned short)18 + (P[1] + P[5]) * (unsigned short)34 +
+                           (P[2] + P[4]) * (unsigned short)48 + P[3] * (unsigned short)56);
+                h.y = as_u((P[2] + P[8]) * (unsigned short)18 + (P[3] + P[7]) * (unsigned short)34 +
+                           (P[4] + P[6]) * (unsigned short)48 + P[5] * (unsigned short)56);
+                if (item < DP_ROWS * (DP_W / 4)) { /* item = r * (DP_W / 4) + g: both arrays are row-major in it */
+                    *reinterpret_cast<uint2*>(hs + 4 * item) = h;
+                    raw[item] = c_;
+                }
+                __builtin_amdgcn_sched_barrier(0); /* one item at a time: interleaving them multiplies the registers in flight */
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         /* intensity centroid over the circular patch: lane & 31 <-> column u; lanes 0..31 take rows -15 .. 0,
          * lanes 32..63 rows 1 .. 15 (row 16 - j of the lower half pairs with row j - 15 of the upper: same
-         * half-width).  All loads are issued before the first use. */
+         * half-width) */
         int m10 = 0, m01 = 0;
         {
             const int u = (lane & 31) - ORB_HALF;
             const bool low = lane >= 32;
-            const uint8_t* col = ip + (size_t)py * I.pitch + px + u;
-            int val[16];
+            /* pixel (px + u, py + v) is byte (px - cx + u + DP_R) of window row (py - cy + v + DP_R + 3) */
+            const uint8_t* col = reinterpret_cast<const uint8_t*>(raw) + (py - cy + DP_R + 3) * DP_W + (px - cx + DP_R) + min(u, ORB_HALF);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int d = orb_umax(15 - j);              /* |v| = 15 - j in both halves ... */
                 const int v = low ? 15 - j : j - 15;         /* ... v = -(15 - j) above, 15 - j below */
                 const bool on = (lane & 31) < ORB_PATCH && u >= -d && u <= d && !(low && j == 15);
-                val[j] = on ? (int)col[(ptrdiff_t)v * I.pitch] : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int v = low ? 15 - j : j - 15;
-                m10 += u * val[j]; m01 += v * val[j];
+                const int val = on ? (int)col[v * DP_W] : 0;
+                m10 += u * val; m01 += v * val;
             }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
         const float angle = fast_atan2f_deg((float)m01, (float)m10);
-        /* steered BRIEF on the blurred level; the centre is recomputed from the scaled position */
-        const float sf = L.scale[l];
-        const float inv = 1.f / sf;
-        const int cx = __float2int_rn(kp->x * inv), cy = __float2int_rn(kp->y * inv);
         float sa, ca;
         sincos_det(angle * (float)(M_PI / 180.f), &sa, &ca);
-        const DImg& Bl = L.blur[l];
-        const uint8_t* bp = Bl.frame(b) + (size_t)cy * Bl.pitch + cx;
+        /* smoothed value at (dx, dy) from the centre: rows dy-3 .. dy+3 of the level are rows dy + DP_R .. + 6 of hs */
+        auto smooth = [&](int dx, int dy) -> int {
+            const unsigned short* c = hs + (dy + DP_R) * DP_W + (dx + DP_R);
+            const u32 v = 18u * ((u32)c[0] + c[6 * DP_W]) + 34u * ((u32)c[DP_W] + c[5 * DP_W]) +
+                          48u * ((u32)c[2 * DP_W] + c[4 * DP_W]) + 56u * (u32)c[3 * DP_W];
+            return (int)((v + (1u << 15)) >> 16);
+        };
         u64 words[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const signed char* pt = &c_pattern[(k * 64 + lane) * 4];
             const float x0 = (float)pt[0] * ca - (float)pt[1] * sa, y0 = (float)pt[0] * sa + (float)pt[1] * ca;
             const float x1 = (float)pt[2] * ca - (float)pt[3] * sa, y1 = (float)pt[2] * sa + (float)pt[3] * ca;
-            const int t0 = bp[(ptrdiff_t)__float2int_rn(y0) * Bl.pitch + __float2int_rn(x0)];
-            const int t1 = bp[(ptrdiff_t)__float2int_rn(y1) * Bl.pitch + __float2int_rn(x1)];
+            const int t0 = smooth(__float2int_rn(x0), __float2int_rn(y0));
+            const int t1 = smooth(__float2int_rn(x1), __float2int_rn(y1));
             words[k] = __ballot(t0 < t1);
         }
         if (lane == 0) {
@@ -571,7 +626,7 @@ __global__ __launch_bounds__(256) void k_orb_desc(OrbLevels L, vfe_orb_kp* __res
 struct OrbWs {
     int nlevels;
     int w[ORB_MAX_LEVELS], h[ORB_MAX_LEVELS], pitch[ORB_MAX_LEVELS], cap[ORB_MAX_LEVELS];
-    size_t raw_off[ORB_MAX_LEVELS], blur_off[ORB_MAX_LEVELS], xtab_off[ORB_MAX_LEVELS], ytab_off[ORB_MAX_LEVELS];
+    size_t raw_off[ORB_MAX_LEVELS], xtab_off[ORB_MAX_LEVELS], ytab_off[ORB_MAX_LEVELS];
     size_t kps_off[ORB_MAX_LEVELS], cnt_off[ORB_MAX_LEVELS], key_off[ORB_MAX_LEVELS], skey_off[ORB_MAX_LEVELS];
     size_t lvlcnt_off, hist_off, hist_bytes, thr_off, fast_off, fast_bytes, total;
 };
@@ -589,7 +644,6 @@ static int orb_layout(int width, int height, int batch, float scale_factor, int 
         L->cap[l] = (L->w[l] * L->h[l]) / 4 + 64;
         const size_t img = align_up((size_t)batch * L->h[l] * L->pitch[l], 256);
         L->raw_off[l] = o; if (l > 0) o += img;   /* level 0 is the caller's image */
-        L->blur_off[l] = o; o += img;
         L->xtab_off[l] = o; o += align_up((size_t)L->w[l] * sizeof(u32), 256);
         L->ytab_off[l] = o; o += align_up((size_t)L->h[l] * sizeof(u32), 256);
         L->kps_off[l] = o; o += align_up((size_t)batch * L->cap[l] * 3 * sizeof(int), 256);
@@ -649,8 +703,6 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
     for (int l = 0; l < nlevels; l++) {
         DImg d; d.border = 0; d.w = W.w[l]; d.h = W.h[l]; d.pitch = W.pitch[l]; d.batch = batch; d.fstride = (size_t)W.h[l] * W.pitch[l];
         d.sub_n = 1; d.sub_gx = 1; d.sub_dx = 0; d.sub_dy = 0;
-        d.data = (uint8_t*)(ws + W.blur_off[l]);
-        L.blur[l] = d;
         if (l == 0) L.raw[0] = to_dimg(img);
         else { d.data = (uint8_t*)(ws + W.raw_off[l]); L.raw[l] = d; }
         L.scale[l] = scales[l];
@@ -716,10 +768,6 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
         VFE_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_orb_emit, dim3(nlevels, batch), dim3(1024), 0, st, L, lvl_count, kps, cap, counts);
         VFE_LAUNCH_CHECK();
-    }
-    {
-        ProfScope prof(VFE_K_ORB_BLUR, st);
-        if ((rc = orb_blur_launch(L.raw, L.blur, nlevels, st))) return rc;
     }
     {
         ProfScope prof(VFE_K_ORB_DESC, st);

@@ -155,11 +155,11 @@ class SLAMEngine:
     def stage_us(self):
         """GPU microseconds per stage of the last frame, {stage name: us}; empty unless stage timing is on."""
         from . import capi
-        out = (C.c_double * 13)()
+        out = (C.c_double * 64)()
         if not lib().vis_engine_stage_us(self._h, out):
             return {}
         L = capi.lib()
-        return {L.vfe_prof_kernel_name(i).decode(): out[i] for i in range(13) if out[i] > 0}
+        return {L.vfe_prof_kernel_name(i).decode(): out[i] for i in range(capi.prof_slots()) if out[i] > 0}
 
     def reset_latency_stats(self):
         lib().vis_engine_reset_latency_stats(self._h)

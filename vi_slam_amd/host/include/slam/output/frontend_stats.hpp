@@ -19,7 +19,7 @@
 
 namespace vi_slam {
 
-constexpr int kFrontEndStages = 13; /* the kernel-timing slots of the GPU library (vfe_prof_kernel_name) */
+constexpr int kFrontEndStages = 12; /* the kernel-timing slots of the GPU library (vfe_prof_kernel_name) */
 
 struct FrontEndFrameStats {
     int64_t timestampNs = 0;   /* sensor timestamp handed to processImage */

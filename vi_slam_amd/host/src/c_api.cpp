@@ -68,11 +68,11 @@ int vis_engine_stats(void* p, double* out9) {
     out9[4] = f.ok ? 1.0 : 0.0; out9[5] = f.tracked; out9[6] = f.detected; out9[7] = f.total; out9[8] = f.latencyUs;
     return have ? 1 : 0;
 }
-/* GPU time per stage of the last frame in microseconds (13 slots; zeros unless stage timing is on); returns 1 if present */
-int vis_engine_stage_us(void* p, double* out13) {
+/* GPU time per stage of the last frame in microseconds (`out`: room for 64 slots, one per name of vfe_prof_kernel_name; zeros unless stage timing is on); returns 1 if present */
+int vis_engine_stage_us(void* p, double* out) {
     FrontEndFrameStats f;
     const bool have = static_cast<Handle*>(p)->engine.frontEndStats().last(f);
-    for (int i = 0; i < kFrontEndStages; i++) out13[i] = have ? f.stageUs[i] : 0.0;
+    for (int i = 0; i < kFrontEndStages; i++) out[i] = have ? f.stageUs[i] : 0.0;
     return have && f.haveStages ? 1 : 0;
 }
 const char* vis_engine_stats_json(void* p) {
