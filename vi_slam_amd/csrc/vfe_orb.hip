@@ -255,6 +255,7 @@ __device__ static inline int row16_sum(int v) {
 
 __global__ __launch_bounds__(64) void k_orb_harris(OrbLevels L) {
     __shared__ u32 s_xy[HARRIS_KP], s_key[HARRIS_KP];
+    __shared__ u32 s_win[4][28];
     const int l = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
     const int cap = L.cap[l];
     const int n = min(L.cnt[l][b], cap);
@@ -310,17 +311,30 @@ __global__ __launch_bounds__(64) void k_orb_harris(OrbLevels L) {
         for (int s0 = 0; s0 < cnt; s0 += 4) { /* wave-uniform */
             const int sv = s0 + row;
             int a = 0, bb = 0, c = 0;
+            /* the survivor's 9 x 9 window (rows y-4 .. y+4, columns x-4 .. x+4, inside the image: keypoints keep 31 pixels
+             * from the rim) goes through LDS as 9 rows of three unaligned dwords, two dwords per lane */
+            u32* win = s_win[row];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (sv < cnt) {
                 const u32 xy = s_xy[sv];
                 const uint8_t* base = ip + (size_t)((int)(xy >> 16) - 4) * pitch + ((int)(xy & 0xFFFFu) - 4);
+                u32 w0, w1 = 0;
+                __builtin_memcpy(&w0, base + (size_t)(sub / 3) * pitch + 4 * (sub % 3), 4);
+                if (sub + 16 < 27) __builtin_memcpy(&w1, base + (size_t)((sub + 16) / 3) * pitch + 4 * ((sub + 16) % 3), 4);
+                win[sub] = w0;
+                if (sub + 16 < 27) win[sub + 16] = w1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (sv < cnt) {
+                const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int p = sub + 16 * r;
                     if (p < 49) {
                         const int py = p / 7, px = p - 7 * py;
-                        const uint8_t* r0 = base + (size_t)py * pitch + px;
-                        const uint8_t* r1 = r0 + pitch;
-                        const uint8_t* r2 = r1 + pitch;
+                        const uint8_t* r0 = wb + py * 12 + px;
+                        const uint8_t* r1 = r0 + 12;
+                        const uint8_t* r2 = r1 + 12;
                         const int Ix = (r1[2] - r1[0]) * 2 + (r0[2] - r0[0]) + (r2[2] - r2[0]);
                         const int Iy = (r2[1] - r0[1]) * 2 + (r2[0] - r0[0]) + (r2[2] - r0[2]);
                         a += Ix * Ix; bb += Iy * Iy; c += Ix * Iy;
