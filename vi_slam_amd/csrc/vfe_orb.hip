@@ -249,9 +249,9 @@ __device__ static inline int row16_sum(int v) {
     return v;
 }
 
-#define HARRIS_KP 16      /* keypoints a wave looks at per pass: few, so that the survivors (often most of them)
-                           * spread over many waves */
-#define HARRIS_CHUNKS 128 /* single-wave workgroups per (level, frame) */
+#define HARRIS_KP 64      /* keypoints a wave looks at per pass: a lane each for the first cut; the few that survive it
+                           * (2 x quota of a level's thousands) then fill the four 16-lane rows of the response pass */
+#define HARRIS_CHUNKS 32  /* single-wave workgroups per (level, frame) */
 
 __global__ __launch_bounds__(64) void k_orb_harris(OrbLevels L) {
     __shared__ u32 s_xy[HARRIS_KP], s_key[HARRIS_KP];
