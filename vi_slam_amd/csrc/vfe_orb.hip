@@ -138,64 +138,122 @@ __global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u3
     }
 }
 
-/* The same resize for 4-byte aligned sources and a scale factor of at most 2, with the gathers in LDS: the byte gathers
- * of the kernel above go through the texture-address path at a handful of lanes per clock, which bounds it at about
- * 1 TB/s.  A workgroup owns RS_SEG output pixels of one row: it copies the two source rows' span into LDS with
- * coalesced dword loads, then every thread gathers its 4 * RS_PX taps from there. */
+/* The same resize for 4-byte aligned sources and a scale factor of at most 2, separable and streaming.  (The byte
+ * gathers of the kernel above go through the texture-address path at a handful of lanes per clock, which bounds it at
+ * about 1 TB/s.)  A workgroup owns RS_SEG output columns and a band of output rows, and a thread RS_PX columns of them
+ * for the whole band, so its source offsets and horizontal weights are loop constants.  Source rows are visited once
+ * each, in ascending order: the workgroup copies the row's span into LDS with coalesced dword loads, every thread gathers
+ * its 2 * RS_PX taps from there and keeps the row's horizontal blend (<= 255 * 256, two pixels per register).  An output
+ * row is the vertical blend of the two newest such rows: one v_dot2 per pixel on (upper, lower) pairs. */
 #define RS_SEG (256 * RS_PX)
 #define RS_SPAN_DW (2 * RS_SEG / 4 + 4) /* dwords per staged source row */
+#define RS_BAND 16                      /* output rows per workgroup */
+typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_orb_resize_rows(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab) {
-    __shared__ u32 s_row[2][RS_SPAN_DW];
-    const int tid = threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    __shared__ u32 s_row[RS_SPAN_DW];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int y0 = blockIdx.y * RS_BAND, y1 = min(y0 + RS_BAND, dst.h);
     const int X0 = blockIdx.x * RS_SEG, xe = min(X0 + RS_SEG, dst.w) - 1; /* first and last output pixel of the workgroup */
     const int s_lo = (int)(xtab[X0] >> 9) & ~3, s_hi = min((int)(xtab[xe] >> 9) + 1, src.w - 1);
     const int ndw = min((s_hi - s_lo) / 4 + 1, RS_SPAN_DW);
-    const u32 ty = ytab[y];
-    const int yo = ty >> 9;
-    const u32 wy1 = ty & 511, wy0 = 256 - wy1;
-    const uint8_t* r0 = src.frame(b) + (size_t)yo * src.pitch + s_lo;
-    const uint8_t* r1 = src.frame(b) + (size_t)min(yo + 1, src.h - 1) * src.pitch + s_lo;
-    for (int i = tid; i < 2 * ndw; i += 256) {
-        const int row = i >= ndw ? 1 : 0, j = i - row * ndw;
-        s_row[row][j] = reinterpret_cast<const u32*>(row ? r1 : r0)[j];
-    }
-    __syncthreads();
     const int x = X0 + RS_PX * tid;
-    if (x >= dst.w) return;
-    u32 tx[RS_PX];
+    const bool live = x < dst.w;
+    /* per thread: byte offsets of the two taps of each pixel within the staged span, weights as 16-bit pairs */
+    u32 a01[RS_PX], W0[RS_PX / 2], W1[RS_PX / 2];
+    {
+        u32 tx[RS_PX];
 #pragma unroll
-    for (int k = 0; k < RS_PX; k += 4) {
-        const uint4 t4 = *reinterpret_cast<const uint4*>(xtab + x + k);
-        tx[k] = t4.x; tx[k + 1] = t4.y; tx[k + 2] = t4.z; tx[k + 3] = t4.w;
+        for (int k = 0; k < RS_PX; k += 4) {
+            const uint4 t4 = live ? *reinterpret_cast<const uint4*>(xtab + x + k) : make_uint4(0, 0, 0, 0);
+            tx[k] = t4.x; tx[k + 1] = t4.y; tx[k + 2] = t4.z; tx[k + 3] = t4.w;
+        }
+#pragma unroll
+        for (int k = 1; k < RS_PX; k++)
+            if (x + k >= dst.w) tx[k] = tx[0];
+        if (!live) {
+#pragma unroll
+            for (int k = 0; k < RS_PX; k++) tx[k] = (u32)s_lo << 9;
+        }
+#pragma unroll
+        for (int k = 0; k < RS_PX; k++) {
+            const int xo = (int)(tx[k] >> 9);
+            a01[k] = (u32)(xo - s_lo) | ((u32)(min(xo + 1, src.w - 1) - s_lo) << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < RS_PX; k += 2) {
+            const u32 w1a = tx[k] & 511, w1b = tx[k + 1] & 511;
+            W1[k / 2] = w1a | (w1b << 16);
+            W0[k / 2] = (256 - w1a) | ((256 - w1b) << 16);
+        }
     }
+    const uint8_t* sp = src.frame(b) + s_lo;
+    /* horizontal blend of source row r: pixels (k, k+1) of the thread as the 16-bit halves of H[k / 2] */
+    constexpr int N_DW = (RS_SPAN_DW + 255) / 256;
+    u32 pv[N_DW]; /* this thread's dwords of source row `prow`, requested ahead */
+    int prow = -1;
+    auto request = [&](int r) {
+        const u32* row = reinterpret_cast<const u32*>(sp + (size_t)r * src.pitch);
 #pragma unroll
-    for (int k = 1; k < RS_PX; k++)
-        if (x + k >= dst.w) tx[k] = tx[0];
-    const uint8_t* l0 = reinterpret_cast<const uint8_t*>(s_row[0]);
-    const uint8_t* l1 = reinterpret_cast<const uint8_t*>(s_row[1]);
-    u32 p[RS_PX][4];
+        for (int i = 0; i < N_DW; i++) pv[i] = tid + 256 * i < ndw ? row[tid + 256 * i] : 0u;
+        prow = r;
+    };
+    auto hrow = [&](int r, u32 (&H)[RS_PX / 2]) {
+        if (r != prow) request(r); /* uniform */
+        __syncthreads(); /* the previous row's gathers are done */
 #pragma unroll
-    for (int k = 0; k < RS_PX; k++) {
-        const int xo = (int)(tx[k] >> 9), a0 = xo - s_lo, a1 = min(xo + 1, src.w - 1) - s_lo;
-        p[k][0] = l0[a0]; p[k][1] = l0[a1]; p[k][2] = l1[a0]; p[k][3] = l1[a1];
-    }
-    u32 o[RS_PX];
+        for (int i = 0; i < N_DW; i++)
+            if (tid + 256 * i < ndw) s_row[tid + 256 * i] = pv[i];
+        request(min(r + 1, src.h - 1)); /* rows are visited in ascending order, mostly one by one */
+        __syncthreads();
+        const uint8_t* l = reinterpret_cast<const uint8_t*>(s_row);
 #pragma unroll
-    for (int k = 0; k < RS_PX; k++) {
-        const u32 wx1 = tx[k] & 511, wx0 = 256 - wx1;
-        const u32 h0 = p[k][0] * wx0 + p[k][1] * wx1;
-        const u32 h1 = p[k][2] * wx0 + p[k][3] * wx1;
-        o[k] = ((h0 * wy0 + h1 * wy1) + (1u << 15)) >> 16;
-    }
-    uint8_t* op = dst.frame(b) + (size_t)y * dst.pitch + x;
-    if (x + RS_PX - 1 < dst.w && ((dst.pitch | dst.fstride | (size_t)(uintptr_t)dst.data) & 3) == 0) {
+        for (int k = 0; k < RS_PX; k += 2) {
+            const u32 p0 = (u32)l[a01[k] & 0xFFFFu] | ((u32)l[a01[k + 1] & 0xFFFFu] << 16);
+            const u32 p1 = (u32)l[a01[k] >> 16] | ((u32)l[a01[k + 1] >> 16] << 16);
+            const rs_u16x2 h = __builtin_bit_cast(rs_u16x2, p0) * __builtin_bit_cast(rs_u16x2, W0[k / 2]) +
+                               __builtin_bit_cast(rs_u16x2, p1) * __builtin_bit_cast(rs_u16x2, W1[k / 2]);
+            H[k / 2] = __builtin_bit_cast(u32, h);
+        }
+    };
+    u32 Ha[RS_PX / 2], Hb[RS_PX / 2]; /* rows ra and min(ra + 1, src.h - 1) */
+    int ra = -2;
+    const bool store4 = ((dst.pitch | dst.fstride | (size_t)(uintptr_t)dst.data) & 3) == 0;
+    for (int y = y0; y < y1; y++) { /* all branches on y are uniform over the workgroup */
+        const u32 ty = ytab[y];
+        const int yo = ty >> 9;
+        const u32 wy1 = ty & 511, wy0 = 256 - wy1;
+        if (yo != ra) {
+            if (yo == ra + 1) {
 #pragma unroll
-        for (int k = 0; k < RS_PX; k += 4)
-            *reinterpret_cast<u32*>(op + k) = o[k] | (o[k + 1] << 8) | (o[k + 2] << 16) | (o[k + 3] << 24);
-    } else {
+                for (int k = 0; k < RS_PX / 2; k++) Ha[k] = Hb[k];
+            } else hrow(yo, Ha);
+            if (yo + 1 <= src.h - 1) hrow(yo + 1, Hb);
+            else {
 #pragma unroll
-        for (int k = 0; k < RS_PX; k++)
-            if (x + k < dst.w) op[k] = (uint8_t)o[k];
+                for (int k = 0; k < RS_PX / 2; k++) Hb[k] = Ha[k];
+            }
+            ra = yo;
+        }
+        if (!live) continue;
+        const u32 wy = wy0 | (wy1 << 16);
+        u32 o[RS_PX];
+#pragma unroll
+        for (int k = 0; k < RS_PX; k += 2) {
+            /* (upper, lower) of pixel k and of pixel k + 1 */
+            const u32 e = __builtin_amdgcn_perm(Hb[k / 2], Ha[k / 2], 0x05040100u), d = __builtin_amdgcn_perm(Hb[k / 2], Ha[k / 2], 0x07060302u);
+            o[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, e), __builtin_bit_cast(rs_u16x2, wy), 1u << 15, false) >> 16;
+            o[k + 1] = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, d), __builtin_bit_cast(rs_u16x2, wy), 1u << 15, false) >> 16;
+        }
+        uint8_t* op = dst.frame(b) + (size_t)y * dst.pitch + x;
+        if (x + RS_PX - 1 < dst.w && store4) {
+#pragma unroll
+            for (int k = 0; k < RS_PX; k += 4)
+                *reinterpret_cast<u32*>(op + k) = o[k] | (o[k + 1] << 8) | (o[k + 2] << 16) | (o[k + 3] << 24);
+        } else {
+#pragma unroll
+            for (int k = 0; k < RS_PX; k++)
+                if (x + k < dst.w) op[k] = (uint8_t)o[k];
+        }
     }
 }
 
@@ -751,7 +809,7 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
             const bool rows_ok = (((uintptr_t)sl.data | (uintptr_t)sl.pitch | (uintptr_t)sl.fstride) & 3) == 0 && sl.sub_n == 1 &&
                                  W.w[l - 1] <= 2 * W.w[l] && W.h[l] <= 65535 && batch <= 65535;
             if (rows_ok)
-                hipLaunchKernelGGL(k_orb_resize_rows, dim3(div_up(W.w[l], RS_SEG), W.h[l], batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab);
+                hipLaunchKernelGGL(k_orb_resize_rows, dim3(div_up(W.w[l], RS_SEG), div_up(W.h[l], RS_BAND), batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab);
             else
                 hipLaunchKernelGGL(k_orb_resize, dim3((per_frame + 255) / 256, batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab, wn, per_frame);
             VFE_LAUNCH_CHECK();
