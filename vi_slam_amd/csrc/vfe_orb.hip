@@ -140,20 +140,24 @@ __global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u3
 
 /* The same resize for 4-byte aligned sources and a scale factor of at most 2, separable and streaming.  (The byte
  * gathers of the kernel above go through the texture-address path at a handful of lanes per clock, which bounds it at
- * about 1 TB/s.)  A workgroup owns RS_SEG output columns and a band of output rows, and a thread RS_PX columns of them
+ * about 1 TB/s.)  A wave owns RS_SEG output columns and a band of output rows, and a lane RS_PX columns of them
  * for the whole band, so its source offsets and horizontal weights are loop constants.  Source rows are visited once
- * each, in ascending order: the workgroup copies the row's span into LDS with coalesced dword loads, every thread gathers
- * its 2 * RS_PX taps from there and keeps the row's horizontal blend (<= 255 * 256, two pixels per register).  An output
+ * each, in ascending order: the wave copies the row's span into its own LDS area with coalesced dword loads, every lane
+ * gathers its 2 * RS_PX taps from there and keeps the row's horizontal blend (<= 255 * 256, two pixels per register).  An output
  * row is the vertical blend of the two newest such rows: one v_dot2 per pixel on (upper, lower) pairs. */
-#define RS_SEG (256 * RS_PX)
-#define RS_SPAN_DW (2 * RS_SEG / 4 + 4) /* dwords per staged source row */
-#define RS_BAND 16                      /* output rows per workgroup */
+#define RS_SEG (64 * RS_PX)             /* output columns per wave */
+#define RS_SPAN_DW (2 * RS_SEG / 4 + 4) /* dwords per staged source row span */
+#define RS_BAND 16                      /* output rows per wave */
+#define RS_AHEAD 1                      /* source rows requested ahead (deeper: more registers, wasted rows at the end of a band, slower) */
 typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_orb_resize_rows(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab) {
-    __shared__ u32 s_row[RS_SPAN_DW];
-    const int tid = threadIdx.x, b = blockIdx.z;
+    __shared__ u32 s_rows[4][RS_SPAN_DW];
+    const int tid = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.z;
+    u32* s_row = s_rows[wv];
     const int y0 = blockIdx.y * RS_BAND, y1 = min(y0 + RS_BAND, dst.h);
-    const int X0 = blockIdx.x * RS_SEG, xe = min(X0 + RS_SEG, dst.w) - 1; /* first and last output pixel of the workgroup */
+    const int X0 = (blockIdx.x * 4 + wv) * RS_SEG; /* first output pixel of the wave */
+    if (X0 >= dst.w) return;                       /* whole waves only: no workgroup barrier below */
+    const int xe = min(X0 + RS_SEG, dst.w) - 1;
     const int s_lo = (int)(xtab[X0] >> 9) & ~3, s_hi = min((int)(xtab[xe] >> 9) + 1, src.w - 1);
     const int ndw = min((s_hi - s_lo) / 4 + 1, RS_SPAN_DW);
     const int x = X0 + RS_PX * tid;
@@ -188,23 +192,33 @@ __global__ __launch_bounds__(256) void k_orb_resize_rows(DImg src, DImg dst, con
     }
     const uint8_t* sp = src.frame(b) + s_lo;
     /* horizontal blend of source row r: pixels (k, k+1) of the thread as the 16-bit halves of H[k / 2] */
-    constexpr int N_DW = (RS_SPAN_DW + 255) / 256;
-    u32 pv[N_DW]; /* this thread's dwords of source row `prow`, requested ahead */
-    int prow = -1;
-    auto request = [&](int r) {
-        const u32* row = reinterpret_cast<const u32*>(sp + (size_t)r * src.pitch);
+    constexpr int N_DW = (RS_SPAN_DW + 63) / 64;
+    /* this lane's dwords of source rows prow .. prow + RS_AHEAD - 1, requested ahead: a row is a few hundred cycles of
+     * work, a trip to memory thousands */
+    u32 pv[RS_AHEAD][N_DW];
+    int prow = -1 - RS_AHEAD;
+    auto request = [&](int r, u32 (&v)[N_DW]) {
+        const u32* row = reinterpret_cast<const u32*>(sp + (size_t)min(r, src.h - 1) * src.pitch);
 #pragma unroll
-        for (int i = 0; i < N_DW; i++) pv[i] = tid + 256 * i < ndw ? row[tid + 256 * i] : 0u;
-        prow = r;
+        for (int i = 0; i < N_DW; i++) v[i] = tid + 64 * i < ndw ? row[tid + 64 * i] : 0u;
     };
     auto hrow = [&](int r, u32 (&H)[RS_PX / 2]) {
-        if (r != prow) request(r); /* uniform */
-        __syncthreads(); /* the previous row's gathers are done */
+        if (r != prow) { /* uniform; rows are visited in ascending order, one by one within a band */
+#pragma unroll
+            for (int d = 0; d < RS_AHEAD; d++) request(r + d, pv[d]);
+            prow = r;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the previous row's gathers are done */
 #pragma unroll
         for (int i = 0; i < N_DW; i++)
-            if (tid + 256 * i < ndw) s_row[tid + 256 * i] = pv[i];
-        request(min(r + 1, src.h - 1)); /* rows are visited in ascending order, mostly one by one */
-        __syncthreads();
+            if (tid + 64 * i < ndw) s_row[tid + 64 * i] = pv[0][i];
+#pragma unroll
+        for (int d = 0; d + 1 < RS_AHEAD; d++)
+#pragma unroll
+            for (int i = 0; i < N_DW; i++) pv[d][i] = pv[d + 1][i];
+        request(r + RS_AHEAD, pv[RS_AHEAD - 1]);
+        prow = r + 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint8_t* l = reinterpret_cast<const uint8_t*>(s_row);
 #pragma unroll
         for (int k = 0; k < RS_PX; k += 2) {
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256) void k_orb_resize_rows(DImg src, DImg dst, con
     u32 Ha[RS_PX / 2], Hb[RS_PX / 2]; /* rows ra and min(ra + 1, src.h - 1) */
     int ra = -2;
     const bool store4 = ((dst.pitch | dst.fstride | (size_t)(uintptr_t)dst.data) & 3) == 0;
-    for (int y = y0; y < y1; y++) { /* all branches on y are uniform over the workgroup */
+    for (int y = y0; y < y1; y++) { /* all branches on y are uniform over the wave */
         const u32 ty = ytab[y];
         const int yo = ty >> 9;
         const u32 wy1 = ty & 511, wy0 = 256 - wy1;
@@ -809,7 +823,7 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
             const bool rows_ok = (((uintptr_t)sl.data | (uintptr_t)sl.pitch | (uintptr_t)sl.fstride) & 3) == 0 && sl.sub_n == 1 &&
                                  W.w[l - 1] <= 2 * W.w[l] && W.h[l] <= 65535 && batch <= 65535;
             if (rows_ok)
-                hipLaunchKernelGGL(k_orb_resize_rows, dim3(div_up(W.w[l], RS_SEG), div_up(W.h[l], RS_BAND), batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab);
+                hipLaunchKernelGGL(k_orb_resize_rows, dim3(div_up(W.w[l], 4 * RS_SEG), div_up(W.h[l], RS_BAND), batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab);
             else
                 hipLaunchKernelGGL(k_orb_resize, dim3((per_frame + 255) / 256, batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab, wn, per_frame);
             VFE_LAUNCH_CHECK();
