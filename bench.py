@@ -274,6 +274,9 @@ def roofline_for(kernels, counters, leg, batch, flop_per_step=None, steps=1):
         if c.get("batch") == batch and dom in c.get("kernels", {}):
             roof["traffic"] = c["kernels"][dom].get("total_bytes")
             roof["traffic_source"] = f"profiles/traffic.json ({counters.get('tag', '')})"
+            if c["kernels"][dom].get("mfma_busy_cycles"):
+                # SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs against the SIMD cycles of the launch at the nominal clock
+                roof["mfma_busy_frac"] = c["kernels"][dom]["mfma_busy_cycles"] / (SIMDS * CLOCK_GHZ * 1e9 * k["avg_ms"] * 1e-3)
         return roof
     roof = {"kernel": dom, "bound": "hbm", "achieved": k["algo_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": k["algo_GBs"] / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": k["algo_bytes_per_launch"],

@@ -69,6 +69,7 @@ def main():
         valu = per_kernel(os.path.join(root, meta["pass"] + "_valu"), "SQ_INSTS_VALU")
         wait = per_kernel(os.path.join(root, meta["pass"] + "_valu"), "SQ_WAIT_INST_ANY")
         wcyc = per_kernel(os.path.join(root, meta["pass"] + "_valu"), "SQ_WAVE_CYCLES")
+        mfma = per_kernel(os.path.join(root, meta["pass"] + "_valu"), "SQ_VALU_MFMA_BUSY_CYCLES")
         kernels = {}
         for slot in slots:
             rd, n = slot_value(fetch, slot, leg)
@@ -76,12 +77,13 @@ def main():
             vi, _ = slot_value(valu, slot, leg)
             wa, _ = slot_value(wait, slot, leg)
             wc, _ = slot_value(wcyc, slot, leg)
+            mf, _ = slot_value(mfma, slot, leg)
             if rd is None and vi is None:
                 continue
             rd_b = 2.0 * 1024.0 * rd if rd is not None else None
             wr_b = 1024.0 * wr if wr is not None else None
             kernels[slot] = {"read_bytes": rd_b, "write_bytes": wr_b, "total_bytes": (rd_b or 0.0) + (wr_b or 0.0), "valu_insts": vi,
-                             "wait_inst_any_quadcycles": wa, "wave_quadcycles": wc, "launches_seen": n}
+                             "wait_inst_any_quadcycles": wa, "wave_quadcycles": wc, "mfma_busy_cycles": mf, "launches_seen": n}
         out["legs"][leg] = {"batch": meta["batch"], "command": meta["command"], "kernels": kernels}
     print(json.dumps(out, indent=1))
 

@@ -24,7 +24,7 @@ declare -A PARGS=( [p256]="--overlap off --steps 4 --warmup 2 --legs main" \
 for p in "${passes[@]}"; do
     run ${p}_fetch "${PARGS[$p]}" --pmc FETCH_SIZE TCC_HIT_sum
     run ${p}_write "${PARGS[$p]}" --pmc WRITE_SIZE TCC_MISS_sum
-    run ${p}_valu "${PARGS[$p]}" --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES
+    run ${p}_valu "${PARGS[$p]}" --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES
     for c in fetch write valu; do
         python3 "$root/tools/pmc_summary.py" "$out/${p}_$c" k_ > "$out/${tag}_${p}_pmc_$c.txt"
     done
