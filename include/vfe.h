@@ -336,11 +336,13 @@ int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long 
 /* vfe_dev_match_knn2 for callers that cannot allocate device memory or bring a workspace: code under HIP graph
  * capture, tight serving loops (one relocalisation query set after the other against a resident map), harnesses that
  * forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, results and error behaviour as
- * vfe_dev_match_knn2 minus the workspace: the per-chunk partial lists go to a VFE_MATCH_NOALLOC_BYTES array that the
- * library's code object reserves on every GPU it runs on (held until the process ends).  The call enqueues its two
- * kernels on `stream` and calls no allocating routine; a device's copy of the array is looked up once, by vfe_create
+ * vfe_dev_match_knn2 minus the workspace: the per-chunk top-2 lists (for train sets of 500 000 rows and more also the
+ * lists of the sampled rows and one floor per query) go to a VFE_MATCH_NOALLOC_BYTES array that the library's code
+ * object reserves on every GPU it runs on (held until the process ends).  The call enqueues its kernels (search and
+ * merge; sample search and merge before them for large train sets) on `stream` and calls no allocating routine; a device's copy of the array is looked up once, by vfe_create
  * or by the first call on that device (make that call before a graph capture).  Sizes whose partial lists do not fit
- * (vfe_match_workspace(nq, nt) > VFE_MATCH_NOALLOC_BYTES: more than ~1 M queries, or tens of millions of train rows)
+ * (vfe_match_workspace(nq, nt) > VFE_MATCH_NOALLOC_BYTES: about 4000 queries against a large train set, which is
+ * searched in 256 chunks, or more queries against a smaller one)
  * are rejected with VFE_E_CAPACITY.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
  * (different streams or threads) race; serialise them or use vfe_dev_match_knn2 with separate workspaces. */
 #define VFE_MATCH_NOALLOC_BYTES (16u << 20)
