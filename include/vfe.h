@@ -341,8 +341,8 @@ int vfe_dev_match_knn2(const uint8_t* query, int nq, const uint8_t* train, long 
  * object reserves on every GPU it runs on (held until the process ends).  The call enqueues its kernels (search and
  * merge; sample search and merge before them for large train sets) on `stream` and calls no allocating routine; a device's copy of the array is looked up once, by vfe_create
  * or by the first call on that device (make that call before a graph capture).  Sizes whose partial lists do not fit
- * (vfe_match_workspace(nq, nt) > VFE_MATCH_NOALLOC_BYTES: about 4000 queries against a large train set, which is
- * searched in 256 chunks, or more queries against a smaller one)
+ * (vfe_match_workspace(nq, nt) > VFE_MATCH_NOALLOC_BYTES: from about 5000 queries against a 10 M-row train set, which
+ * is searched in a few hundred chunks; ask vfe_match_workspace)
  * are rejected with VFE_E_CAPACITY.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
  * (different streams or threads) race; serialise them or use vfe_dev_match_knn2 with separate workspaces. */
 #define VFE_MATCH_NOALLOC_BYTES (16u << 20)

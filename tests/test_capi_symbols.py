@@ -42,6 +42,11 @@ def test_workspace_queries_are_host_only():
     assert L.vfe_frontend_workspace(1920, 1080, 2, 1000) > 2 * L.vfe_good_features_workspace(1920, 1080, 1, 1000, 1000) - 4096
     assert L.vfe_fast_workspace(752, 480, 1) > 0 and L.vfe_orb_workspace(752, 480, 1, 1.2, 8) > 0
     assert L.vfe_match_workspace(2000, 2000) > 0
+    # one top-2 list per (query, chunk) in two int arrays; a large train set adds the sample's lists and a floor per query,
+    # and the relocalisation shape (2000 queries, 10 M rows) still fits the array of the entry point that allocates nothing
+    assert L.vfe_match_workspace(0, 100) == 0 and L.vfe_match_workspace(5, 0) >= 5 * 2 * 4 * 2
+    small, large = L.vfe_match_workspace(2000, 100_000), L.vfe_match_workspace(2048, 10_000_000)
+    assert 2000 * 200 * 16 <= small < large <= capi.MATCH_NOALLOC_BYTES < L.vfe_match_workspace(6000, 10_000_000)
     assert L.vfe_lk_max_level(752, 480, 21, 3) == 3 and L.vfe_lk_max_level(40, 40, 21, 3) == 0
 
 

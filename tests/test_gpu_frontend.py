@@ -414,6 +414,53 @@ def test_frontend_step_sequence(cuda, w, h, n, d, levels):
             assert ntr > 0.8 * n
 
 
+def test_frontend_step_under_graph_capture(cuda):
+    """vfe_dev_frontend_step only enqueues (kernels, memsets, the fork to and join from the helper stream), so a caller may
+    capture it into a HIP graph: three captured steps replayed give the point sets of three directly enqueued steps."""
+    import torch
+    w, h, n, d, levels, q, B = 640, 360, 200, 12, 3, 0.01, 3
+    seq = [[synth.scene(synth.BASE_SEED + 70 + b, w, h, t) for t in range(4)] for b in range(B)]
+    frames = [to_dev([seq[b][t] for b in range(B)], cuda) for t in range(4)]
+
+    def fresh():
+        fe = capi.FrontendStep(B, h, w, n, levels, 21, quality=q, min_distance=d, device=cuda)
+        pyr = [capi.alloc_pyramid(frames[0], levels), capi.alloc_pyramid(frames[0], levels)]
+        capi.build_pyramid(pyr[0])
+        gf = capi.GoodFeatures(B, h, w, n, device=cuda)
+        c, _, cnt = gf(frames[0], q, d)
+        fe.pts.copy_(c); fe.n_pts.copy_(cnt)
+        return fe, pyr
+
+    fe, pyr = fresh()
+    cur = 0
+    for t in range(1, 4):
+        pyr[cur ^ 1][0] = frames[t]
+        fe.step(pyr[cur], pyr[cur ^ 1])
+        cur ^= 1
+    torch.cuda.synchronize()
+    want_pts, want_n = fe.pts.clone(), fe.n_pts.clone()
+
+    fe, pyr = fresh()
+    torch.cuda.synchronize()
+    graphs, cur = [], 0
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for t in range(1, 4):
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin()
+            pyr[cur ^ 1][0] = frames[t]
+            fe.step(pyr[cur], pyr[cur ^ 1])
+            g.capture_end()
+            graphs.append(g)
+            cur ^= 1
+    torch.cuda.synchronize()
+    for g in graphs:  # capturing executed nothing
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(fe.n_pts, want_n) and torch.equal(fe.pts, want_pts)
+    assert int(want_n.min()) > n // 2
+
+
 def test_frontend_step_many_streams_tile_order(cuda):
     """Enough points in the batch (streams x capacity >= 16384) for the tracker to take each frame's points tile by tile:
     48 streams that repeat three sequences, capacity 350; every stream equals the oracle's sequence and its repeats."""

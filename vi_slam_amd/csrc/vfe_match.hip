@@ -357,7 +357,8 @@ struct MatchGeom {
     int s_chunk, s_chunks; long long s_rows;
     long long lists; /* top-2 lists per query that the final merge reads */
 };
-#define MM_SAMPLE_CHUNK 128          /* rows per sample chunk */
+#define MM_SAMPLE_CHUNK 256          /* rows per sample chunk (half as many sample chunks as main chunks: their lists
+                                      * are workspace, and the sample is a few per cent of the work) */
 #define MM_SAMPLE_MIN_ROWS 500000    /* train sets from this size on are searched with a floor */
 static MatchGeom match_geom(int nq, long long nt) {
     MatchGeom g;
@@ -366,7 +367,7 @@ static MatchGeom match_geom(int nq, long long nt) {
     long long want = 256 / (long long)g.qblocks;
     if (want < 1) want = 1;
     g.s_chunk = MM_SAMPLE_CHUNK; g.s_chunks = 0; g.s_rows = 0;
-    if (nt >= MM_SAMPLE_MIN_ROWS) { g.s_chunks = (int)want; g.s_rows = (long long)g.s_chunks * g.s_chunk; }
+    if (nt >= MM_SAMPLE_MIN_ROWS) { g.s_chunks = (int)((want + 1) / 2); g.s_rows = (long long)g.s_chunks * g.s_chunk; }
     const long long rest = nt - g.s_rows;
     long long chunk = ((rest + want - 1) / want + 31) / 32 * 32;
     if (chunk < 256) chunk = 256;
