@@ -197,6 +197,25 @@ def test_match_knn2_batch_equals_per_pair_calls(cuda):
         assert (idx[b, nq[b]:] == -1).all() and (dist[b, nq[b]:] == 0x7fffffff).all() and not good[b, nq[b]:].any()
 
 
+def test_match_knn2_batch_train_set_longer_than_one_round(cuda):
+    """A batched pair whose train set exceeds what one pass of the search can index (65536 rows): the workgroup scans it in
+    rounds and merges them; ties across the round boundary keep the lower index."""
+    import torch
+    qcap, tcap = 100, 70_000
+    q = synth.descriptors(71, qcap)[None]
+    t = synth.descriptors(72, tcap)[None].copy()
+    for i in range(40):
+        t[0, (i * 1733 + 5) % tcap] = synth.flip_bits(300 + i, q[0, i], i % 9)
+    t[0, 69_000] = t[0, 100] = q[0, 50]          # identical rows either side of the boundary
+    nq, nt = np.array([qcap], np.int32), np.array([tcap], np.int32)
+    idx, dist, good = capi.match_knn2_batch(torch.from_numpy(q).to(cuda), torch.from_numpy(nq).to(cuda),
+                                            torch.from_numpy(t).to(cuda), torch.from_numpy(nt).to(cuda), 0.7)
+    ridx, rdist = ora.match_knn2(q[0], t[0])
+    assert np.array_equal(idx[0].cpu().numpy(), ridx) and np.array_equal(dist[0].cpu().numpy(), rdist)
+    assert list(ridx[50]) == [100, 69_000] and list(rdist[50]) == [0, 0]
+    assert np.array_equal(good[0].cpu().numpy(), ora.ratio_test(ridx, rdist, 0.7))
+
+
 def test_match_sharded_merge_equals_single_scan(cuda):
     """cfg5 shape at reduced size: a map split into 8 contiguous shards, per-shard top-2 merged by
     (dist, idx) equals one scan over the whole map; planted near-duplicates are found."""
