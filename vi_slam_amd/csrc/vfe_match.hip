@@ -32,17 +32,20 @@ __device__ static inline void top2_insert(int d, int i, int& d0, int& i0, int& d
  * descriptors of its QT x 32 queries in registers for the whole chunk (the B operand: the query is the column of the
  * result, i.e. it sits on the lane, lanes l and l + 32 hold the rows 4h .. 4h + 3 (+8, +16, +24) of a column's
  * results).  The train rows pass through LDS 32 at a time: all threads expand a tile of packed rows (1 KB) into
- * nibbles (4 KB) while the previous tile is being multiplied; each wave reads the tile as its A operand.  How the 256
+ * nibbles (4 KB, through a 256-entry table in LDS) while the previous tile is being multiplied; each wave reads the
+ * tile as its A operand.  How the 256
  * positions are dealt to instructions and lane halves does not matter as long as both operands use the same deal:
  * lane half h takes descriptor words 4h .. 4h + 3, instruction s the word 4h + s.
  *
  * Top-2 per lane: a result's key is product + (32767 - (16 * step + register)) / 32768, i.e. among equal products the
  * row met first (the lower train index) has the larger key, and the key says which row it was; products are even
- * integers of magnitude <= 256, so the sum is exact in fp32 (9 + 15 bits).  The running pair (k1 >= k2) is updated by
+ * integers of magnitude <= 256, so the sum is exact in fp32 (9 + 15 bits).  The position fraction is the C input of a
+ * tile's first MFMA (16 registers, stepped once per 32 rows), so the accumulators come out as keys; the matrix pipe adds
+ * it exactly (checked against the CPU scan on sets with thousands of ties).  The running pair (k1 >= k2) is updated by
  * k2 = med3(k1, k2, key), k1 = max(k1, key).  Most tiles cannot change any lane's pair (after t tiles a tile's chance
- * is ~32 / t per query), so a tile first takes the maximum of its 16 raw products per lane and the update runs only
- * if some lane's maximum exceeds its k2 (a product equal to floor(k2) belongs to a later row and loses).  Rows past
- * the end of the chunk get a bias that keeps them below every real key. */
+ * is ~32 / t per query), and the vector work of a tile has to fit beside its four MFMAs, so a tile first takes the
+ * maximum of its 16 keys per lane and the update runs only if some lane's maximum exceeds its k2.  Rows past the end
+ * of the chunk get a C input that keeps them below every real key. */
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
