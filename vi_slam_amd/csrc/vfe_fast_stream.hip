@@ -3,7 +3,7 @@
  * different sizes (the levels of an ORB pyramid), so that small levels fill the gaps large ones leave.
  *
  * One wavefront owns a strip of 62 x 4 columns (lanes 0 and 63 are halo) and walks down a band of rows.
- * A lane keeps the last seven image rows as three dwords each (its own four bytes and the neighbours'),
+ * A lane keeps the last image rows as three dwords each (its own four bytes and the neighbours'),
  * so every pixel of the 16-pixel circle is a byte of a register.  Two horizontally adjacent pixels are
  * handled together in packed 16-bit arithmetic.
  *
@@ -23,8 +23,9 @@
  * three rows stay in registers for the 3x3 suppression; keypoints of a row segment are numbered in raster
  * order with ballots and written to the segment's slot together with the segment's count.
  *
- * The row loop is unrolled seven times so that the image ring's register slots are compile-time constants;
- * a band is 7k - 8 rows high so that every wave runs whole periods. */
+ * The row loop is unrolled nine times so that the register slots of the image ring (a row is kept for six steps)
+ * and of the three suppression rows are compile-time constants; a band is 9k - 8 rows high so that every wave runs
+ * whole turns. */
 #include "vfe_common.h"
 #include "vfe_fast.h"
 #include <type_traits>
@@ -57,17 +58,20 @@ __device__ static inline s2v win_pair(const u32 (&row)[3], int i) {
 #define FQ_K 8               /* rows between the compass test of a row and its suppression */
 #define FQ_IR 16             /* image ring (>= FQ_K + 7: rows c-3 of the oldest queued centre c .. the row being loaded); a power of two */
 #define FQ_SR 16             /* score ring (>= FQ_K + 2: from a row's compass test to its last use as a neighbour); a power of two */
-#define FQ_AHEAD 7           /* image rows requested ahead: a row step is a few hundred cycles, a trip to HBM thousands */
+#define FQ_PERIOD 9          /* steps per turn of the unrolled row loop: the register ring of image rows must hold a row for six
+                              * steps, the three suppression rows rotate with period three */
+#define FQ_AHEAD FQ_PERIOD   /* image rows requested ahead: a row step is a few hundred cycles, a trip to HBM thousands */
 #define FQ_QCAP 256          /* queue entries (63 left over + one row's 128 at most) */
 static_assert(FQ_IR >= FQ_K + 7 && FQ_SR >= FQ_K + 2 && (FQ_IR & (FQ_IR - 1)) == 0 && (FQ_SR & (FQ_SR - 1)) == 0 && FQ_IR <= 32 && FQ_SR <= 16,
               "ring sizes: powers of two that cover the delay, and ring slots must fit the 5 + 4 bits of a queue entry");
-static_assert(FQ_AHEAD == 7, "the prefetch ring shares the period of the unrolled row loop");
+static_assert(FQ_AHEAD == FQ_PERIOD && FQ_PERIOD % 3 == 0 && FQ_PERIOD >= 7, "the prefetch ring and the suppression rows share the period of the unrolled row loop");
 
 /* necessary condition on the compass pixels of the pair (PX, PX+1): true if either pixel can be a corner.  The ring
- * slot PH holds the newest row (centre + 3), so centre + dy sits in slot (PH + 4 + dy) mod 7. */
+ * slot PH holds the newest row (centre + 3), so centre + dy sits in slot (PH - 3 + dy) mod FQ_PERIOD; only the rows
+ * centre - 3, centre, centre + 3 are read. */
 template <int PX, int PH>
-__device__ static inline bool fast_compass_pair(const u32 (&R)[7][3], int t, u32 sm) {
-#define FS_ROW(dy) R[(PH + 4 + (dy) + 7) % 7]
+__device__ static inline bool fast_compass_pair(const u32 (&R)[FQ_PERIOD][3], int t, u32 sm) {
+#define FS_ROW(dy) R[(PH - 3 + (dy) + 2 * FQ_PERIOD) % FQ_PERIOD]
     const s2v v = win_pair(FS_ROW(0), PX + 4);
     const s2v d0 = v - win_pair(FS_ROW(FS_DY(0)), PX + FS_DX(0) + 4), d4 = v - win_pair(FS_ROW(FS_DY(4)), PX + FS_DX(4) + 4);
     const s2v d8 = v - win_pair(FS_ROW(FS_DY(8)), PX + FS_DX(8) + 4), d12 = v - win_pair(FS_ROW(FS_DY(12)), PX + FS_DX(12) + 4);
@@ -144,12 +148,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             rep[k] = out_lane && x >= border && x < W - border;
         }
 
-        u32 R[7][3]; /* image rows: left neighbour's, own, right neighbour's dword; the row of step t in slot t mod 7 */
-        u32 SC[3][3]; /* score rows M-1 .. M+1: pixel pairs (0,1), (2,3) as 16-bit values, and s[-1] | s[4] << 16 */
+        u32 R[FQ_PERIOD][3]; /* image rows: left neighbour's, own, right neighbour's dword; the row of step t in slot t mod FQ_PERIOD */
+        /* the three newest score rows, the row fetched in step t in slot t mod 3: pixel pairs (0,1), (2,3) as 16-bit values,
+         * and per pair the largest horizontal neighbour without (H2) and with (H3) the pixel itself */
+        u32 SP[3][2], H2[3][2], H3[3][2];
 #pragma unroll
-        for (int i = 0; i < 7; i++) R[i][0] = R[i][1] = R[i][2] = 0;
+        for (int i = 0; i < FQ_PERIOD; i++) R[i][0] = R[i][1] = R[i][2] = 0;
 #pragma unroll
-        for (int i = 0; i < 3; i++) SC[i][0] = SC[i][1] = SC[i][2] = 0;
+        for (int i = 0; i < 3; i++) SP[i][0] = SP[i][1] = H2[i][0] = H2[i][1] = H3[i][0] = H3[i][1] = 0;
         int qn = 0, q_head = 0, first_c = 0; /* queue state (wave-uniform); first_c = centre index of the oldest entry */
 
         auto load_row = [&](int yy) -> u32 {
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             return (u32)row[min(max(X0, 0), W - 1)] | ((u32)row[min(max(X0 + 1, 0), W - 1)] << 8) |
                    ((u32)row[min(max(X0 + 2, 0), W - 1)] << 16) | ((u32)row[min(max(X0 + 3, 0), W - 1)] << 24);
         };
-        u32 pre[FQ_AHEAD]; /* rows y0 - 4 + t .. + 6 on their way; the row of step t sits in slot t mod 7 */
+        u32 pre[FQ_AHEAD]; /* rows y0 - 4 + t .. + FQ_AHEAD - 1 on their way; the row of step t sits in slot t mod FQ_PERIOD */
 #pragma unroll
         for (int i = 0; i < FQ_AHEAD; i++) pre[i] = load_row(y0 - 4 + i);
 
@@ -199,47 +205,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         auto drain_due = [&](int t) {
             while (qn >= 64 || (qn > 0 && first_c <= t - 3 - FQ_K)) drain(t - 3);
         };
-        /* suppression and output of row index m = t - 4 - FQ_K (image row M); scores of rows <= m + 1 are final */
-        auto suppress = [&](int t, int n_rows) {
+        /* suppression and output of row index m = t - 4 - FQ_K (image row M); scores of rows <= m + 1 are final.  s3c = t mod 3. */
+        auto suppress = [&](auto s3c, int t, int n_rows) {
+            constexpr int SN = decltype(s3c)::value, SCN = (SN + 2) % 3, SO = (SN + 1) % 3; /* slots of rows m + 1, m, m - 1 */
             const int cn = t - 3 - FQ_K; /* newest score row needed */
-#pragma unroll
-            for (int i = 0; i < 2; i++) { SC[i][0] = SC[i + 1][0]; SC[i][1] = SC[i + 1][1]; SC[i][2] = SC[i + 1][2]; }
             {
-                u32 s01 = 0, s23 = 0;
+                u32 p01 = 0, p23 = 0;
                 if (cn >= 3 && cn < n_rows) { /* rows that went through the compass test (wave-uniform) */
                     const u32 w4 = sc_ring[cn & (FQ_SR - 1)][lane];
-                    s01 = __builtin_amdgcn_perm(0u, w4, 0x0c010c00u);
-                    s23 = __builtin_amdgcn_perm(0u, w4, 0x0c030c02u);
+                    p01 = __builtin_amdgcn_perm(0u, w4, 0x0c010c00u);
+                    p23 = __builtin_amdgcn_perm(0u, w4, 0x0c030c02u);
                 }
-                SC[2][0] = s01; SC[2][1] = s23;
-                const u32 sl = lane_up_u(s23) >> 16, sr = lane_down_u(s01) & 0xFFFFu;
-                SC[2][2] = sl | (sr << 16);
+                const u32 e = (lane_up_u(p23) >> 16) | (lane_down_u(p01) << 16); /* s[-1] | s[4] << 16 */
+                const u2v L01 = as_uh(__builtin_amdgcn_perm(p01, e, 0x05040100u));    /* (s[-1], s0) */
+                const u2v M12 = as_uh(__builtin_amdgcn_perm(p23, p01, 0x05040302u));  /* (s1, s2) */
+                const u2v R23 = as_uh(__builtin_amdgcn_perm(e, p23, 0x07060302u));    /* (s3, s4) */
+                const u2v h01 = __builtin_elementwise_max(L01, M12), h23 = __builtin_elementwise_max(M12, R23);
+                SP[SN][0] = p01; SP[SN][1] = p23;
+                H2[SN][0] = __builtin_bit_cast(u32, h01); H2[SN][1] = __builtin_bit_cast(u32, h23);
+                H3[SN][0] = __builtin_bit_cast(u32, __builtin_elementwise_max(h01, as_uh(p01)));
+                H3[SN][1] = __builtin_bit_cast(u32, __builtin_elementwise_max(h23, as_uh(p23)));
             }
             const int m = cn - 1, M = y0 - 4 + m;
             if (m < 4 || M >= H || M >= y0 + band_h) return; /* wave-uniform */
             int total = 0;
-            if (__ballot((SC[1][0] | SC[1][1]) != 0) != 0 && M >= border && M < H - border) {
-                u2v nb01, nb23; /* largest of the eight neighbours */
-                {
-                    u2v h01[3], h23[3];
-#pragma unroll
-                    for (int i = 0; i < 3; i++) {
-                        const u32 p01 = SC[i][0], p23 = SC[i][1], e = SC[i][2];
-                        const u2v L01 = as_uh(__builtin_amdgcn_perm(p01, e, 0x05040100u));    /* (s[-1], s0) */
-                        const u2v M12 = as_uh(__builtin_amdgcn_perm(p23, p01, 0x05040302u));  /* (s1, s2) */
-                        const u2v R23 = as_uh(__builtin_amdgcn_perm(e, p23, 0x07060302u));    /* (s3, s4) */
-                        if (i == 1) {
-                            h01[i] = __builtin_elementwise_max(L01, M12);
-                            h23[i] = __builtin_elementwise_max(M12, R23);
-                        } else {
-                            h01[i] = __builtin_elementwise_max(__builtin_elementwise_max(L01, M12), as_uh(p01));
-                            h23[i] = __builtin_elementwise_max(__builtin_elementwise_max(M12, R23), as_uh(p23));
-                        }
-                    }
-                    nb01 = __builtin_elementwise_max(__builtin_elementwise_max(h01[0], h01[1]), h01[2]);
-                    nb23 = __builtin_elementwise_max(__builtin_elementwise_max(h23[0], h23[1]), h23[2]);
-                }
-                const u2v c01 = as_uh(SC[1][0]), c23 = as_uh(SC[1][1]);
+            if (__ballot((SP[SCN][0] | SP[SCN][1]) != 0) != 0 && M >= border && M < H - border) {
+                /* largest of the eight neighbours */
+                const u2v nb01 = __builtin_elementwise_max(__builtin_elementwise_max(as_uh(H3[SO][0]), as_uh(H2[SCN][0])), as_uh(H3[SN][0]));
+                const u2v nb23 = __builtin_elementwise_max(__builtin_elementwise_max(as_uh(H3[SO][1]), as_uh(H2[SCN][1])), as_uh(H3[SN][1]));
+                const u2v c01 = as_uh(SP[SCN][0]), c23 = as_uh(SP[SCN][1]);
                 const bool kp[4] = {rep[0] && c01.x > nb01.x, rep[1] && c01.y > nb01.y, rep[2] && c23.x > nb23.x, rep[3] && c23.y > nb23.y};
                 const unsigned long long m0 = __ballot(kp[0]), m1 = __ballot(kp[1]), m2 = __ballot(kp[2]), m3 = __ballot(kp[3]);
                 total = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
@@ -251,7 +245,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     pos = __builtin_amdgcn_mbcnt_hi((u32)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m2, pos));
                     pos = __builtin_amdgcn_mbcnt_hi((u32)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m3, pos));
                     u32* dst = tmp + (seg0 + (size_t)M * strips_x) * FS_ROWCAP;
-                    const u32 sc[4] = {SC[1][0] & 0xFFFFu, SC[1][0] >> 16, SC[1][1] & 0xFFFFu, SC[1][1] >> 16};
+                    const u32 sc[4] = {SP[SCN][0] & 0xFFFFu, SP[SCN][0] >> 16, SP[SCN][1] & 0xFFFFu, SP[SCN][1] >> 16};
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                         if (kp[k]) { dst[pos] = (u32)(4 * (lane - 1) + k) | (sc[k] << 8); pos++; }
@@ -292,24 +286,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             if constexpr (ST < 2) return;
             drain_due(t);
-            suppress(t, T - 3);
+            suppress(ic<PH % 3>{}, t, T - 3);
         };
 
         step(ic<0>{}, ic<0>{}, 0); step(ic<1>{}, ic<0>{}, 1); step(ic<2>{}, ic<0>{}, 2); step(ic<3>{}, ic<0>{}, 3);
-        step(ic<4>{}, ic<0>{}, 4); step(ic<5>{}, ic<0>{}, 5); step(ic<6>{}, ic<1>{}, 6);
-        int t0 = 7;
-        for (; t0 < T; t0 += 7) {
+        step(ic<4>{}, ic<0>{}, 4); step(ic<5>{}, ic<0>{}, 5); step(ic<6>{}, ic<2>{}, 6); step(ic<7>{}, ic<2>{}, 7); step(ic<8>{}, ic<2>{}, 8);
+        int t0 = FQ_PERIOD;
+        for (; t0 < T; t0 += FQ_PERIOD) {
             if (y0 - 7 + t0 >= H - 3) break; /* no row left that could be scored (wave-uniform) */
-            step(ic<0>{}, ic<2>{}, t0); step(ic<1>{}, ic<2>{}, t0 + 1); step(ic<2>{}, ic<2>{}, t0 + 2); step(ic<3>{}, ic<2>{}, t0 + 3);
-            step(ic<4>{}, ic<2>{}, t0 + 4); step(ic<5>{}, ic<2>{}, t0 + 5); step(ic<6>{}, ic<2>{}, t0 + 6);
+            step(ic<0>{}, ic<2>{}, t0); step(ic<1>{}, ic<2>{}, t0 + 1); step(ic<2>{}, ic<2>{}, t0 + 2);
+            step(ic<3>{}, ic<2>{}, t0 + 3); step(ic<4>{}, ic<2>{}, t0 + 4); step(ic<5>{}, ic<2>{}, t0 + 5);
+            step(ic<6>{}, ic<2>{}, t0 + 6); step(ic<7>{}, ic<2>{}, t0 + 7); step(ic<8>{}, ic<2>{}, t0 + 8);
         }
         /* the rows still on their way: no more loads, only what is queued and the suppression behind it.  Score rows of
-         * indices >= t0 - 3 never had a compass test: suppress() reads them as 0. */
+         * indices >= t0 - 3 never had a compass test: suppress() reads them as 0.  t0 is a multiple of three. */
         const int t_end = min(band_h, H - y0) + 8 + FQ_K;
-        for (int t = t0; t < t_end; t++) {
-            drain_due(t);
-            suppress(t, t0 - 3);
+        int t = t0;
+        for (; t + 2 < t_end; t += 3) {
+            drain_due(t); suppress(ic<0>{}, t, t0 - 3);
+            drain_due(t + 1); suppress(ic<1>{}, t + 1, t0 - 3);
+            drain_due(t + 2); suppress(ic<2>{}, t + 2, t0 - 3);
         }
+        if (t < t_end) { drain_due(t); suppress(ic<0>{}, t, t0 - 3); }
+        if (t + 1 < t_end) { drain_due(t + 1); suppress(ic<1>{}, t + 1, t0 - 3); }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* the next item reuses the rings */
     }
 }
@@ -368,8 +367,8 @@ __global__ __launch_bounds__(1024) void k_fast_scan_stream(FastSet S, const uint
 }
 
 static int fast_set_geometry(FastSet& S, int batch) {
-    /* band height 7k - 8; the tallest that still gives every SIMD several items */
-    static const int heights[5] = {62, 34, 27, 20, 13};
+    /* band height 9k - 8 (whole turns of the unrolled row loop); the tallest that still gives every SIMD several items */
+    static const int heights[5] = {64, 37, 28, 19, 10};
     int band_h = 13;
     for (int i = 0; i < 5; i++) {
         long long items = 0;
