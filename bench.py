@@ -44,9 +44,9 @@ MAP_ROWS, N_QUERIES = 10_000_000, 2000
 # DPP, perm, med3, popcount, min/max and shifts occupy a SIMD's issue port for ~4.2 cycles per wave64 instruction at any
 # occupancy; only v_add/v_fma f32, v_add_u32, v_xor, v_mov reach ~2.2 with two or more waves per SIMD.
 VALU_CYCLES_PER_INST, SIMDS, CLOCK_GHZ = 4.2, 1024, 2.4
-# average issue cost of a kernel's instruction mix where it is known to differ: the matcher spends 8 of its 19 instructions per
-# pair on 2.2-cycle xors.  For the others 4.2 is used for every instruction, which overstates the time at the ceiling (and so
-# the fraction of it reached) by whatever share of their instructions belongs to the 2.2-cycle classes.
+# average issue cost of a kernel's instruction mix where it is known to differ (none at present): 4.2 is used for every
+# instruction, which overstates the time at the ceiling (and so the fraction of it reached) by whatever share of a kernel's
+# instructions belongs to the 2.2-cycle classes.
 VALU_CYCLES_BY_KERNEL = {}
 MFMA_FP4_PEAK_TFLOPS = 10000.0   # dense block-scaled fp4 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), the matcher's instruction
 MATCH_FLOP_PER_PAIR = 512        # one descriptor pair = a 256-element product of +-1 vectors
@@ -510,10 +510,9 @@ def run_reloc_leg(rk, steps, warmup, counters):
            "collective": "all_gather (RCCL)" if rk.world > 1 and not rk.gloo else ("all_gather (gloo rehearsal)" if rk.world > 1 else "none (one shard)"),
            "roofline": roof, "kernels": kernels}
     if "k_match" in kernels:
-        # xor + accumulating popcount per 32-bit word, median + minimum on packed keys: 19 VALU instructions per 64 pairs
+        # the search kernel alone (sample + main launch of a step), without all-gather and merges
         km = kernels["k_match"]
-        rate = N_QUERIES * rows / (km["avg_ms"] * 1e-3)
-        out["k_match_pairs_per_s"] = rate
+        out["k_match_pairs_per_s"] = N_QUERIES * rows / (km["avg_ms"] * 1e-3 * km["launches"] / steps)
     return out
 
 
