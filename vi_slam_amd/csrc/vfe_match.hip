@@ -370,18 +370,23 @@ struct MatchGeom {
 static MatchGeom match_geom(int nq, long long nt) {
     MatchGeom g;
     g.qt = nq > 1024 ? 8 : nq > 512 ? 4 : nq > 256 ? 2 : 1;
-    g.qblocks = (unsigned)((nq + g.qt * 256 - 1) / (g.qt * 256));
-    long long want = 256 / (long long)g.qblocks;
-    if (want < 1) want = 1;
-    g.s_chunk = MM_SAMPLE_CHUNK; g.s_chunks = 0; g.s_rows = 0;
-    if (nt >= MM_SAMPLE_MIN_ROWS) { g.s_chunks = (int)((want + 1) / 2); g.s_rows = (long long)g.s_chunks * g.s_chunk; }
-    const long long rest = nt - g.s_rows;
-    long long chunk = ((rest + want - 1) / want + 31) / 32 * 32;
-    if (chunk < 256) chunk = 256;
-    if (chunk > MM_MAX_ROWS) chunk = MM_MAX_ROWS;
-    g.chunk = (int)chunk;
-    g.nchunks = rest > 0 ? (rest + chunk - 1) / chunk : 1;
-    g.lists = g.nchunks + (g.s_chunks ? 1 : 0);
+    for (;;) {
+        g.qblocks = (unsigned)((nq + g.qt * 256 - 1) / (g.qt * 256));
+        long long want = 256 / (long long)g.qblocks;
+        if (want < 1) want = 1;
+        g.s_chunk = MM_SAMPLE_CHUNK; g.s_chunks = 0; g.s_rows = 0;
+        if (nt >= MM_SAMPLE_MIN_ROWS) { g.s_chunks = (int)((want + 1) / 2); g.s_rows = (long long)g.s_chunks * g.s_chunk; }
+        const long long rest = nt - g.s_rows;
+        long long chunk = ((rest + want - 1) / want + 31) / 32 * 32;
+        if (chunk < 128) chunk = 128;
+        if (chunk > MM_MAX_ROWS) chunk = MM_MAX_ROWS;
+        g.chunk = (int)chunk;
+        g.nchunks = rest > 0 ? (rest + chunk - 1) / chunk : 1;
+        g.lists = g.nchunks + (g.s_chunks ? 1 : 0);
+        /* a small train set gives few chunks: fewer query tiles per wave, i.e. more query blocks, keep the chip busy */
+        if (g.qt == 1 || (long long)g.qblocks * g.nchunks >= 128) break;
+        g.qt >>= 1;
+    }
     return g;
 }
 
