@@ -183,7 +183,7 @@ AuxStream* vfe_aux_stream() {
 }
 /* Independent kernels side by side.  The big kernels of the library are bound by vector-instruction issue, yet the waves
  * of two of them fill each other's stalls and tails: the detector's eigenvalue pass beside pyramid + tracker gains 6-11 %
- * of a front-end step from one stream to 256, the ORB blur beside FAST + selection likewise.  On by default for every
+ * of a front-end step from one stream to 256.  On by default for every
  * batch size; vfe_set_overlap(0) or VFE_OVERLAP=0 in the environment keeps everything on the caller's stream (e.g. to time
  * the kernels one at a time). */
 static std::atomic<int> g_overlap{-1}; /* -1: not set yet, take the environment's word */
