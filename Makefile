@@ -32,6 +32,9 @@ $(LIBDIR)/libvfe_synth.so: $(CSRC)/synth.cpp | $(LIBDIR)
 # one object per source so that `make -j` compiles them side by side (no device code is shared across files)
 OBJDIR ?= build/obj
 HIP_OBJS = $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRCS))
+# the eigenvalue kernel chooses between packed and plain float operations by hand (issue cost per element is the same, the
+# packed form needs its operands in register pairs); the SLP vectoriser would re-pack the plain ones behind extra moves
+$(OBJDIR)/vfe_gftt_eig.o: HIPFLAGS += -fno-slp-vectorize
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<

@@ -39,6 +39,13 @@ __device__ static inline float max3(float a, float b, float c) {
     return d;
 }
 
+/* a + b as a plain (unpacked) add whatever the compiler would like to pair it with */
+__device__ static inline float add1(float a, float b) {
+    float d;
+    asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 __device__ static inline float min2(float a, float b) { /* no NaNs here: one instruction, no quieting */
     float d;
     asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -74,12 +81,12 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
         const uint8_t* ip = img.frame(b);
         u32 seen = 0;
         float prune = 0.f, wmax = 0.f;
-        float prune_half = -1.f; /* rows whose every min(a, c) is <= this are skipped (negative: none) */
+        float prune_twice = -1.f; /* rows whose every min(sxx, syy) = 2 min(a, c) is <= this are skipped (negative: none) */
         if (!WRITE_MAP) {
             seen = __hip_atomic_load(&frame_max[b * GF_CSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             wmax = __uint_as_float(seen);
             prune = (float)((double)wmax * quality);
-            prune_half = prune * 0.5f - 2e-7f;
+            prune_twice = 2.f * (prune * 0.5f - 2e-7f);
         }
         int nbuf = 0;
         const int seg = t_item % GF_NSEG;
@@ -169,11 +176,14 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
                 }
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++) {
+                    /* plain adds: a packed add costs as much as two plain ones, the pairs (l, c0), (c1, c2), (c3, r) would
+                     * have to be assembled with moves first, and a plain add takes the neighbour lane's value directly
+                     * (DPP operand) */
                     const f2 c01 = cv[pl][0], c23 = cv[pl][1];
                     const float l = lane_up(c23.y), r = lane_down(c01.x);
-                    const f2 Lp = {l, c01.x}, M = {c01.y, c23.x}, Rp = {c23.y, r};
-                    HS[s0][pl][0] = (Lp + c01) + M;  /* (l + c0) + c1, (c0 + c1) + c2 */
-                    HS[s0][pl][1] = (M + c23) + Rp;  /* (c1 + c2) + c3, (c2 + c3) + r */
+                    const float m01 = add1(c01.x, c01.y), m12 = add1(c01.y, c23.x), m23 = add1(c23.x, c23.y);
+                    HS[s0][pl][0] = f2{add1(l + c01.x, c01.y), add1(m01, c23.x)};
+                    HS[s0][pl][1] = f2{add1(m12, c23.y), m23 + r};
                 }
             }
             if constexpr (ST < 3) return;
@@ -181,14 +191,15 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
             {
                 const int E = yy - 2;
                 const bool yin = !YB || (E >= 0 && E < H);
-                f2 a_[2], c_[2], xy_[2], s_[2];
+                /* a = sxx / 2, c = syy / 2 are never formed: halving is exact, so a + c = (sxx + syy) / 2 and
+                 * (a - c)^2 = (sxx - syy)^2 / 4 round to the same floats, and min(a, c) <= x is min(sxx, syy) <= 2 x */
+                f2 sxx_[2], syy_[2], xy_[2], s_[2];
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
-                    const f2 sxx = (HS[s2][0][p] + HS[s1][0][p]) + HS[s0][0][p];
+                    sxx_[p] = (HS[s2][0][p] + HS[s1][0][p]) + HS[s0][0][p];
                     xy_[p] = (HS[s2][1][p] + HS[s1][1][p]) + HS[s0][1][p];
-                    const f2 syy = (HS[s2][2][p] + HS[s1][2][p]) + HS[s0][2][p];
-                    a_[p] = sxx * 0.5f; c_[p] = syy * 0.5f;
-                    s_[p] = a_[p] + c_[p];
+                    syy_[p] = (HS[s2][2][p] + HS[s1][2][p]) + HS[s0][2][p];
+                    s_[p] = (sxx_[p] + syy_[p]) * 0.5f;
                 }
                 /* A row in which no pixel of the wave can pass the quality threshold needs neither the square roots nor a
                  * place in the maximum or the candidate test.  The smaller eigenvalue is at most 2 min(a, c); as computed
@@ -200,9 +211,9 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
                  * true one would.  Steady-state rows of the candidate pass only. */
                 bool dead = false;
                 if constexpr (!WRITE_MAP && !YB) {
-                    const float tm = max3(max3(min2(a_[0].x, c_[0].x), min2(a_[0].y, c_[0].y), min2(a_[1].x, c_[1].x)),
-                                          min2(a_[1].y, c_[1].y), 0.f);
-                    dead = (__ballot(tm > prune_half) & inner_lanes) == 0;
+                    const float tm = max3(max3(min2(sxx_[0].x, syy_[0].x), min2(sxx_[0].y, syy_[0].y), min2(sxx_[1].x, syy_[1].x)),
+                                          min2(sxx_[1].y, syy_[1].y), 0.f);
+                    dead = (__ballot(tm > prune_twice) & inner_lanes) == 0;
                 }
                 dead_row[s0] = dead;
                 if (dead) {
@@ -210,8 +221,9 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
                 } else {
 #pragma unroll
                     for (int p = 0; p < 2; p++) {
-                        const f2 d = a_[p] - c_[p];
-                        const f2 q = d * d + xy_[p] * xy_[p];
+                        const f2 d = sxx_[p] - syy_[p];
+                        const f2 dd = d * d, bb = xy_[p] * xy_[p];
+                        const f2 q = {__builtin_fmaf(dd.x, 0.25f, bb.x), __builtin_fmaf(dd.y, 0.25f, bb.y)}; /* the quarter is exact: one rounding, that of the sum */
                         const f2 rt = sqrt_rn2(q);
                         f2 e = s_[p] - rt;
                         if (!yin) e = f2{-1.f, -1.f};
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
                 return;
             }
             if (dead_row[s1]) return; /* nothing above prune in this row: no maximum to raise, no candidate */
-            wmax = max3(wmax, max3(v[0], v[1], v[2]), v[3]);
+            wmax = max3(wmax, HM[s1][0].y, HM[s1][1].x); /* the row's horizontal maxima over pixels 0-2 and 1-3 are in the lane already */
             if (N < 1 || N > H - 2) return;
             const float m[4] = {max3(HM[s2][0].x, HM[s1][0].x, HM[s0][0].x), max3(HM[s2][0].y, HM[s1][0].y, HM[s0][0].y),
                                 max3(HM[s2][1].x, HM[s1][1].x, HM[s0][1].x), max3(HM[s2][1].y, HM[s1][1].y, HM[s0][1].y)};
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
                     seen = max(max(seen, now), __float_as_uint(wm)); /* positive floats order like their bit patterns */
                     wmax = fmaxf(wmax, __uint_as_float(seen));
                     prune = (float)((double)__uint_as_float(seen) * quality);
-                    prune_half = prune * 0.5f - 2e-7f;
+                    prune_twice = 2.f * (prune * 0.5f - 2e-7f);
                 }
             }
         }
