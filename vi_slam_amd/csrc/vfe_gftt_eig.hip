@@ -46,6 +46,12 @@ __device__ static inline float add1(float a, float b) {
     return d;
 }
 
+__device__ static inline float mul1(float a, float b) { /* likewise a plain multiply */
+    float d;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 __device__ static inline float min2(float a, float b) { /* no NaNs here: one instruction, no quieting */
     float d;
     asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -79,6 +85,8 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
         const int X0 = sxi * EV_OUT + 4 * (lane - 2); /* image column of this lane's pixel 0 */
         const int y0 = byi * band_h, y1 = min(y0 + band_h, H);
         const uint8_t* ip = img.frame(b);
+        /* 0x00020000: untyped 32-bit data; every access of a frame (plus the row past its end) lies inside the range */
+        const __amdgpu_buffer_rsrc_t frame_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ip, 0, (H + 1) * img.pitch, 0x00020000);
         u32 seen = 0;
         float prune = 0.f, wmax = 0.f;
         float prune_twice = -1.f; /* rows whose every min(sxx, syy) = 2 min(a, c) is <= this are skipped (negative: none) */
@@ -127,7 +135,10 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
         /* the lane's four pixels of image row yy (reflect-101) */
         auto load_row = [&](int yy) -> u32 {
             const uint8_t* row = ip + (size_t)reflect101(yy, H) * img.pitch;
-            if ((ALIGNED && !EDGE) || fast_load) return *reinterpret_cast<const uint32_t*>(row + X0);
+            /* away from the rim: the frame as a raw buffer, the row as the scalar offset, the lane's column as the vector
+             * offset -- no vector address arithmetic at all */
+            if (ALIGNED && !EDGE) return (u32)__builtin_amdgcn_raw_buffer_load_b32(frame_rsrc, X0, reflect101(yy, H) * img.pitch, 0);
+            if (fast_load) return *reinterpret_cast<const uint32_t*>(row + X0);
             if (dead_load) return 0u;
             return (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
                    ((u32)row[reflect101(X0 + 2, W)] << 16) | ((u32)row[reflect101(X0 + 3, W)] << 24);
@@ -151,11 +162,13 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
                 const float fl = (float)(l >> 24), fr = (float)(r & 255u);
                 const float b0 = (float)(rC & 255u), b1 = (float)((rC >> 8) & 255u);
                 const float b2 = (float)((rC >> 16) & 255u), b3 = (float)(rC >> 24);
-                /* pixel k sees columns k-1, k, k+1: pairs of left, centre and right neighbours */
-                const f2 A = {fl, b0}, B = {b0, b1}, C = {b1, b2}, B2 = {b2, b3}, C2 = {b3, fr};
+                /* pixel k sees columns k-1, k, k+1.  The six values sit in three register pairs, which serve as the left and
+                 * right neighbours of both pixel pairs; the centre pairs (b0, b1), (b2, b3) straddle them, so their products
+                 * are plain multiplies (same issue cost per element, no moves to assemble the pairs) */
+                const f2 A = {fl, b0}, C = {b1, b2}, C2 = {b3, fr};
                 RX[s0][0] = C - A; RX[s0][1] = C2 - C;
-                RY[s0][0] = k_c * B + k_o * (A + C);
-                RY[s0][1] = k_c * B2 + k_o * (C + C2);
+                RY[s0][0] = f2{mul1(k_c, b0), mul1(k_c, b1)} + k_o * (A + C);
+                RY[s0][1] = f2{mul1(k_c, b2), mul1(k_c, b3)} + k_o * (C + C2);
             }
             if constexpr (ST < 2) return;
             /* ---- gradient products at row P = yy - 1 and their horizontal 3-sums ---- */
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
                     sxx_[p] = (HS[s2][0][p] + HS[s1][0][p]) + HS[s0][0][p];
                     xy_[p] = (HS[s2][1][p] + HS[s1][1][p]) + HS[s0][1][p];
                     syy_[p] = (HS[s2][2][p] + HS[s1][2][p]) + HS[s0][2][p];
-                    s_[p] = (sxx_[p] + syy_[p]) * 0.5f;
+                    s_[p] = sxx_[p] + syy_[p]; /* twice a + c */
                 }
                 /* A row in which no pixel of the wave can pass the quality threshold needs neither the square roots nor a
                  * place in the maximum or the candidate test.  The smaller eigenvalue is at most 2 min(a, c); as computed
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
                         const f2 dd = d * d, bb = xy_[p] * xy_[p];
                         const f2 q = {__builtin_fmaf(dd.x, 0.25f, bb.x), __builtin_fmaf(dd.y, 0.25f, bb.y)}; /* the quarter is exact: one rounding, that of the sum */
                         const f2 rt = sqrt_rn2(q);
-                        f2 e = s_[p] - rt;
+                        f2 e = __builtin_elementwise_fma(s_[p], f2{0.5f, 0.5f}, -rt); /* (a + c) - root: the halving is exact, one rounding */
                         if (!yin) e = f2{-1.f, -1.f};
                         if (EDGE) {
                             if (!xin[2 * p]) e.x = -1.f;
