@@ -318,7 +318,7 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
         VFE_HIP(hipStreamWaitEvent(st, aux->join, 0));
         guard.joined = true;
     } else if ((rc = gf_eig_phase(&next_levels[0], cap, quality, min_distance, cap, ws + L.gf_off, L.gf_bytes, st))) return rc;
-    if ((rc = gf_select_phase(&next_levels[0], cap, quality, min_distance, pts, n_pts, cap, corners, nullptr, counts,
-                              ws + L.gf_off, L.gf_bytes, st))) return rc;
-    return vfe_dev_append_points(pts, n_pts, cap, batch, corners, counts, cap, stream);
+    /* the selection appends what it accepts to the tracked points itself (one launch less at the serial end of the step) */
+    return gf_select_phase(&next_levels[0], cap, quality, min_distance, pts, n_pts, cap, corners, nullptr, counts,
+                           ws + L.gf_off, L.gf_bytes, st, true);
 }

@@ -30,9 +30,12 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
                      double quality, hipStream_t st);
 
 /* the two halves of vfe_dev_good_features: the first depends on the image only and may be enqueued on another
- * stream, the second needs the tracked points; same workspace, same parameters */
+ * stream, the second needs the tracked points; same workspace, same parameters.  `append` (seed arrays with max_corners
+ * slots per frame): the accepted corners are also written behind each frame's seeds and n_seeds grows by their number,
+ * i.e. the selection does what vfe_dev_append_points would do next */
 int gf_eig_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance, int seed_cap, void* workspace,
                  size_t workspace_bytes, hipStream_t st);
 int gf_select_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance,
                     const float* seeds_xy, const int* n_seeds, int seed_cap,
-                    float* corners_xy, float* scores, int* counts, void* workspace, size_t workspace_bytes, hipStream_t st);
+                    float* corners_xy, float* scores, int* counts, void* workspace, size_t workspace_bytes, hipStream_t st,
+                    bool append);

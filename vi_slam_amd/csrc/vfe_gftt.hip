@@ -49,6 +49,10 @@ struct SelParams {
     float* corners;
     float* scores;
     int* counts;
+    /* append mode (both or neither): the accepted corners also go behind the frame's tracked points, append_pts[b][n + i]
+     * with n the clamped seed count, and the count becomes n + accepted -- the seeds' own arrays, [batch][seed_cap] */
+    float* append_pts;
+    int* append_n;
 };
 
 __device__ static inline u32 ld_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     const int ns = (p.seeds && p.n_seeds) ? max(0, min(p.n_seeds[b], p.seed_cap)) : 0;
     const int limit = max(0, p.max_corners - ns);
     if (limit == 0) { /* nothing to add: the frame keeps its tracked points */
-        if (tid == 0) p.counts[b] = 0;
+        if (tid == 0) { p.counts[b] = 0; if (p.append_n) p.append_n[b] = ns; }
         return;
     }
     /* Tracked points occupy the min-distance grid first.  A candidate within min_distance of one of
@@ -374,6 +378,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
                     float* c = p.corners + ((size_t)b * p.max_corners + my) * 2;
                     c[0] = (float)x; c[1] = (float)y;
                     if (p.scores) p.scores[(size_t)b * p.max_corners + my] = __uint_as_float((u32)(key >> 32));
+                    if (p.append_pts) {
+                        float* a = p.append_pts + ((size_t)b * p.seed_cap + ns + my) * 2;
+                        a[0] = (float)x; a[1] = (float)y;
+                    }
                 }
                 if (lds_walk) {
                     /* two taken candidates may share a cell: everyone writes the head, whoever reads its own node back
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
         U = T;
         m_batch = SEL_M;
     }
-    if (tid == 0) p.counts[b] = n_acc;
+    if (tid == 0) { p.counts[b] = n_acc; if (p.append_n) p.append_n[b] = ns + n_acc; }
 }
 
 /* workspace layout (all offsets 256-byte aligned) */
@@ -441,6 +449,10 @@ static GfWs gf_layout(int w, int h, int batch, int max_corners, int seed_cap, do
     L.hdr_off = o; o += align_up((size_t)batch * (1 + GF_NSEG) * GF_CSTRIDE * sizeof(u32), 256);
     L.heads_off = o; o += align_up((size_t)batch * L.gw * L.gh * sizeof(u32), 256);
     L.zero_bytes = o;
+    /* the selection keeps both min-distance grids in LDS when they fit, and then never touches the grid heads in memory:
+     * only the counters need clearing (the same three conditions as in k_gftt_select, on the capacities) */
+    if (!L.use_grid || (L.gw * L.gh <= SEED_CELLS && L.gw * L.gh <= WALK_CELLS && seed_cap <= SEED_NODES && max_corners <= WALK_NODES))
+        L.zero_bytes = L.heads_off;
     {   /* a segment receives every GF_NSEG-th (strip, band) item; each can emit one key per pixel */
         const EigGeom g = eig_geom(w, h, batch);
         L.seg_cap = (u32)div_up(g.strips_x * g.bands_y, GF_NSEG) * (u32)(EV_OUT * g.band_h);
@@ -506,7 +518,8 @@ int gf_eig_phase(const vfe_dimg* img, int max_corners, double quality, double mi
 /* second half: ordered selection against the tracked points */
 int gf_select_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance,
                     const float* seeds_xy, const int* n_seeds, int seed_cap,
-                    float* corners_xy, float* scores, int* counts, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                    float* corners_xy, float* scores, int* counts, void* workspace, size_t workspace_bytes, hipStream_t st,
+                    bool append) {
     GfWs L;
     int rc = gf_check(img, max_corners, quality, min_distance, seeds_xy, n_seeds, &seed_cap, corners_xy, counts, workspace,
                       workspace_bytes, &L);
@@ -524,6 +537,12 @@ int gf_select_phase(const vfe_dimg* img, int max_corners, double quality, double
     p.node_cap = L.node_cap;
     p.seeds = seeds_xy; p.n_seeds = n_seeds; p.seed_cap = seed_cap;
     p.corners = corners_xy; p.scores = scores; p.counts = counts;
+    p.append_pts = nullptr; p.append_n = nullptr;
+    if (append) {
+        /* the accepted corners fit behind the seeds: at most max_corners - n of them are taken */
+        VFE_REQUIRE(seeds_xy && n_seeds && seed_cap == max_corners, "append mode needs the seed arrays with max_corners slots per frame");
+        p.append_pts = const_cast<float*>(seeds_xy); p.append_n = const_cast<int*>(n_seeds);
+    }
     {
         ProfScope prof(VFE_K_GFTT_SELECT, st);
         hipLaunchKernelGGL(k_gftt_select, dim3(img->batch), dim3(SEL_THREADS), 0, st, p);
@@ -542,7 +561,7 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     if (rc) return rc;
     if ((rc = gf_eig_phase(img, max_corners, quality, min_distance, sc, workspace, workspace_bytes, (hipStream_t)stream))) return rc;
     return gf_select_phase(img, max_corners, quality, min_distance, seeds_xy, n_seeds, sc, corners_xy, scores, counts, workspace,
-                           workspace_bytes, (hipStream_t)stream);
+                           workspace_bytes, (hipStream_t)stream, false);
 }
 
 extern "C" int vfe_dev_min_eigen_map(const vfe_dimg* img, float* eig, void* stream) {
