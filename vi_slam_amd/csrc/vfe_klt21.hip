@@ -81,6 +81,20 @@ __device__ static inline void fetch_patch(const DImg& im, const uint8_t* fp, int
     const bool padded = im.border >= KLT_NEED_BORDER;
     const bool cols_in = padded || (x0 >= 0 && x0 + 24 <= im.w);
     const int x = x0 + 8 * P.pk;
+    /* Patches that lie inside the image (or its border) for every point of the wave -- nearly all -- take one address
+     * computation and a pitch step per row; the general form reflects row by row (wave-uniform choice). */
+    const bool inside = cols_in && (padded || (y0 >= 0 && y0 + NROWS <= im.h));
+    if (__builtin_amdgcn_ballot_w64(P.on && !inside) == 0) {
+        const uint8_t* src = fp + (ptrdiff_t)(y0 + P.pr) * im.pitch + x;
+        const ptrdiff_t step = (ptrdiff_t)4 * im.pitch;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            v[i] = make_uint2(0u, 0u);
+            if (P.on && (4 * i + 4 <= NROWS || 4 * i + P.pr < NROWS)) v[i] = ldu64(src);
+            src += step;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const int row = 4 * i + P.pr;
