@@ -46,7 +46,10 @@ enum Cls {
     C_PK_FMA_F32, C_PK_MUL_F32, C_PK_ADD_F32, C_MOV_DPP_ROW, C_MOV_DPP_WAVE, C_ADD_DPP_ROW, C_RSQ, C_SQRT, C_RCP, C_CVT_F32_I32,
     C_MOV, C_MUL_F32, C_SUB_F32, C_MAX_F32, C_MIN_F32, C_AND, C_OR, C_LSHL_V, C_LSHR, C_ASHR, C_BFE, C_CVT_UB0, C_CVT_UB3,
     C_CNDMASK_S, C_SUB_U32, C_ADD3, C_LSHL_ADD, C_LSHL_OR, C_MUL_U24, C_ALIGNBIT, C_PK_SUB_I16, C_PK_LSHR_B16, C_SAD_U8, C_FMAC_F32,
-    C_MAD_I24, C_MAX_U32, C_CVT_U32_F32, C_RNDNE, C_CVT_I32_F32, C_MAX_I32, C_ADD_I16, C_MAD_U16, C_COUNT
+    C_MAD_I24, C_MAX_U32, C_CVT_U32_F32, C_RNDNE, C_CVT_I32_F32, C_MAX_I32, C_ADD_I16, C_MAD_U16,
+    /* 64-bit integer address arithmetic and double precision (register pairs) */
+    C_MAD_U64_U32, C_MAD_I64_I32, C_LSHL_ADD_U64, C_CVT_F64_I32, C_CVT_F32_F64, C_CVT_F64_F32, C_FMA_F64, C_MUL_F64, C_ADD_F64,
+    C_PK_MOV, C_MOV_B64, C_COUNT
 };
 static const char* kNames[C_COUNT] = {
     "v_add_f32", "v_fma_f32", "v_max3_f32", "v_add_u32", "v_xor_b32", "v_and_or_b32", "v_lshlrev_b32", "v_min_u32", "v_med3_u32",
@@ -56,7 +59,9 @@ static const char* kNames[C_COUNT] = {
     "v_cvt_f32_i32", "v_mov_b32", "v_mul_f32", "v_sub_f32", "v_max_f32", "v_min_f32", "v_and_b32", "v_or_b32", "v_lshlrev_b32 (vgpr shift)",
     "v_lshrrev_b32", "v_ashrrev_i32", "v_bfe_u32", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte3", "v_cndmask_b32 (sgpr mask)", "v_sub_u32",
     "v_add3_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_mul_u32_u24", "v_alignbit_b32", "v_pk_sub_i16", "v_pk_lshrrev_b16", "v_sad_u8",
-    "v_fmac_f32", "v_mad_i32_i24", "v_max_u32", "v_cvt_u32_f32", "v_rndne_f32", "v_cvt_i32_f32", "v_max_i32", "v_add_u16", "v_mad_u16"};
+    "v_fmac_f32", "v_mad_i32_i24", "v_max_u32", "v_cvt_u32_f32", "v_rndne_f32", "v_cvt_i32_f32", "v_max_i32", "v_add_u16", "v_mad_u16",
+    "v_mad_u64_u32", "v_mad_i64_i32", "v_lshl_add_u64", "v_cvt_f64_i32", "v_cvt_f32_f64", "v_cvt_f64_f32", "v_fma_f64", "v_mul_f64", "v_add_f64",
+    "v_pk_mov_b32", "v_mov_b64"};
 
 template <int CLS>
 __global__ __launch_bounds__(1024) void k_issue(long long* __restrict__ stamps, uint32_t* __restrict__ sink, int trips, uint32_t seed) {
@@ -139,6 +144,37 @@ __global__ __launch_bounds__(1024) void k_issue(long long* __restrict__ stamps, 
         else if (CLS == C_MAX_I32) { OP32("v_max_i32 %0, %0, %1") }
         else if (CLS == C_ADD_I16) { OP32("v_add_u16 %0, %0, %1") }
         else if (CLS == C_MAD_U16) { OP32("v_mad_u16 %0, %0, %1, %2") }
+        else if (CLS == C_MAD_U64_U32) {
+            _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {
+                _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[i]) : "v"(c0), "v"(c1) : "vcc");
+            }
+        }
+        else if (CLS == C_MAD_I64_I32) {
+            _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {
+                _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(q[i]) : "v"(c0), "v"(c1) : "vcc");
+            }
+        }
+        else if (CLS == C_LSHL_ADD_U64) { OP64("v_lshl_add_u64 %0, %0, 0, %1") }
+        else if (CLS == C_CVT_F64_I32) {
+            _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {
+                _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(q[i]) : "v"(r[i]));
+            }
+        }
+        else if (CLS == C_CVT_F32_F64) {
+            _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {
+                _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(r[i]) : "v"(q[i]));
+            }
+        }
+        else if (CLS == C_CVT_F64_F32) {
+            _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {
+                _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(q[i]) : "v"(r[i]));
+            }
+        }
+        else if (CLS == C_FMA_F64) { OP64("v_fma_f64 %0, %0, %1, %2") }
+        else if (CLS == C_MUL_F64) { OP64("v_mul_f64 %0, %0, %1") }
+        else if (CLS == C_ADD_F64) { OP64("v_add_f64 %0, %0, %1") }
+        else if (CLS == C_PK_MOV) { OP64("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]") }
+        else if (CLS == C_MOV_B64) { OP64("v_mov_b64 %0, %1") }
     }
     const long long t1 = clock64();
     uint32_t acc = 0;

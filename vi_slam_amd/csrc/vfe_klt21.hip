@@ -64,10 +64,11 @@ __device__ static inline int row_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); /* row_ror 8 */
     return v;
 }
-/* float(sum over the row of 16 lanes), rounded once from the exact integer total */
+/* float(sum over the row of 16 lanes), rounded once from the exact integer total: both halves are exact as floats
+ * (|hi| < 2^20, lo < 2^20) and the fused multiply-add rounds hi * 65536 + lo once */
 __device__ static inline float row_sum_to_float(int v) {
     const int lo = row_sum(v & 0xFFFF), hi = row_sum(v >> 16);
-    return (float)__builtin_fma((double)hi, 65536.0, (double)lo);
+    return __builtin_fmaf((float)hi, 65536.f, (float)lo);
 }
 
 /* Twelve of the 16 lanes of a point request NROWS rows x 24 bytes starting at image position
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
             const DImg& J = p.next[level];
             const uint8_t* ip = I.frame(b);
             const uint8_t* jp = J.frame(b);
-            const float sc = (float)(1. / (double)(1 << level));
+            const float sc = __uint_as_float((unsigned)(127 - level) << 23); /* 2^-level */
             float px = ppx * sc, py = ppy * sc, nx, ny;
             if (level == max_level) {
                 if (p.use_initial) { nx = outx * sc; ny = outy * sc; }
@@ -402,7 +403,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
                 nx += dx; ny += dy;
                 outx = nx + half; outy = ny + half;
                 bool done = ((double)dx * (double)dx + (double)dy * (double)dy <= p.epsilon);
-                if (!done && j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                /* (double)|x| < 0.01  <=>  |x| <= the float below 0.01, which is (float)0.01 */
+                const float kSmall = 0.01f;
+                static_assert((double)0.01f < 0.01, "the float nearest 0.01 lies below it");
+                if (!done && j > 0 && fabsf(dx + pdx) <= kSmall && fabsf(dy + pdy) <= kSmall) {
                     outx -= dx * 0.5f; outy -= dy * 0.5f;
                     done = true;
                 }
