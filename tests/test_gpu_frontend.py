@@ -141,7 +141,10 @@ def test_eigen_pass_every_band_tail(cuda):
 
 @pytest.mark.parametrize("w,h,n,q,d", [(752, 480, 150, 0.01, 30), (752, 480, 200, 0.01, 10), (640, 480, 200, 0.007, 10),
                                        (320, 240, 500, 0.01, 1), (320, 240, 300, 0.05, 0), (1920, 1080, 1000, 0.01, 20),
-                                       (200, 100, 50, 0.01, 7.5)])
+                                       (200, 100, 50, 0.01, 7.5),
+                                       # widths that end inside a lane's four columns and inside / just past a 240-column strip
+                                       (201, 100, 80, 0.01, 3), (202, 90, 80, 0.01, 3), (203, 64, 80, 0.01, 3), (241, 70, 80, 0.01, 2),
+                                       (239, 70, 80, 0.01, 2), (479, 50, 80, 0.01, 2), (482, 50, 80, 0.01, 2), (9, 40, 10, 0.01, 1)])
 def test_good_features_bit_exact(cuda, w, h, n, q, d):
     imgs = [synth.scene(synth.BASE_SEED + 2, w, h, 0), synth.noise(5, w, h), np.full((h, w), 128, np.uint8)]
     gf = capi.GoodFeatures(len(imgs), h, w, n, device=cuda)

@@ -113,6 +113,23 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
         }
         const bool fast_load = ALIGNED && X0 >= 0 && X0 + 3 < W;
         const bool dead_load = X0 + 3 < -4 || X0 > W + 4;
+        /* Rim strips with dword-aligned rows: every lane loads one in-row dword (its own where that lies inside the row) and
+         * the columns outside the image -- only x = -2, -1 and W, W + 1 feed anything that is kept -- are filled in from the
+         * lane's own and its two neighbours' dwords by two byte permutes with per-lane selectors, fixed for the item: the
+         * reflected source column 2 W - 2 - x or -x is at most one lane away.  No byte loads, no per-row reflection. */
+        const int X0c = min(max(X0, 0), (W - 1) & ~3);
+        u32 sel_prev = 0x07060504u, sel_next = 0x03020100u; /* identity: the lane's own dword */
+        if (ALIGNED && edge_strip) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = X0 + k;
+                int s = k; /* byte of the own dword; columns nobody reads keep whatever the lane loaded */
+                if (x < 0 || x >= W) s = reflect101(x, W) - X0;
+                if (s >= -4 && s < 0) sel_prev = (sel_prev & ~(0xFFu << (8 * k))) | ((u32)(s + 4) << (8 * k));
+                else if (s >= 0 && s < 4) sel_prev = (sel_prev & ~(0xFFu << (8 * k))) | ((u32)(4 + s) << (8 * k));
+                else if (s >= 4 && s < 8) sel_next = (sel_next & ~(0xFFu << (8 * k))) | ((u32)s << (8 * k));
+            }
+        }
 
         /* the item body, specialised (wave-uniformly) for strips away from the rim: all loads are plain
          * dword loads and no column needs a flag */
@@ -138,6 +155,7 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
             /* away from the rim: the frame as a raw buffer, the row as the scalar offset, the lane's column as the vector
              * offset -- no vector address arithmetic at all */
             if (ALIGNED && !EDGE) return (u32)__builtin_amdgcn_raw_buffer_load_b32(frame_rsrc, X0, reflect101(yy, H) * img.pitch, 0);
+            if (ALIGNED) return (u32)__builtin_amdgcn_raw_buffer_load_b32(frame_rsrc, X0c, reflect101(yy, H) * img.pitch, 0);
             if (fast_load) return *reinterpret_cast<const uint32_t*>(row + X0);
             if (dead_load) return 0u;
             return (u32)row[reflect101(X0, W)] | ((u32)row[reflect101(X0 + 1, W)] << 8) |
@@ -156,8 +174,12 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
             {
                 /* the row was requested a step ago; request the next one now (the row after the band's last is a
                  * valid address too and never used) */
-                const u32 rC = pre;
+                u32 rC = pre;
                 pre = load_row(yy + 1);
+                if (ALIGNED && EDGE) { /* columns outside the image from the neighbours' (raw) dwords */
+                    const u32 t = __builtin_amdgcn_perm(rC, lane_up_u(rC), sel_prev);
+                    rC = __builtin_amdgcn_perm(lane_down_u(rC), t, sel_next);
+                }
                 const u32 l = lane_up_u(rC), r = lane_down_u(rC);
                 const float fl = (float)(l >> 24), fr = (float)(r & 255u);
                 const float b0 = (float)(rC & 255u), b1 = (float)((rC >> 8) & 255u);
