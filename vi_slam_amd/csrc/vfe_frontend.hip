@@ -9,7 +9,7 @@
 /* stable compaction of surviving tracks, one workgroup per stream */
 __global__ __launch_bounds__(256) void k_compact(const float* __restrict__ pts, const uint8_t* __restrict__ status,
                                                  const int* __restrict__ n_pts, int cap, int W, int H, int border,
-                                                 float* __restrict__ out, int* __restrict__ out_n) {
+                                                 float* __restrict__ out, int* __restrict__ out_n, int* __restrict__ out_n2) {
     __shared__ int s_w[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = n_pts ? max(0, min(n_pts[b], cap)) : cap;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_compact(const float* __restrict__ pts, 
         }
         base += tot;
     }
-    if (tid == 0) out_n[b] = base;
+    if (tid == 0) { out_n[b] = base; if (out_n2) out_n2[b] = base; }
 }
 
 __global__ __launch_bounds__(256) void k_append(float* __restrict__ pts, int* __restrict__ n_pts, int cap,
@@ -62,7 +62,16 @@ extern "C" int vfe_dev_compact_tracks(const float* pts, const uint8_t* status, c
     VFE_REQUIRE(out_pts != pts, "compaction is out of place");
     ProfScope prof(VFE_K_COMPACT, (hipStream_t)stream);
     hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, (hipStream_t)stream, pts, status, n_pts, cap, width, height,
-                       border, out_pts, out_n);
+                       border, out_pts, out_n, (int*)nullptr);
+    VFE_LAUNCH_CHECK();
+    return VFE_OK;
+}
+
+/* the same with a second copy of the counts (the front-end step reports them as n_tracked: no copy launch behind it) */
+static int compact_tracks2(const float* pts, const uint8_t* status, const int* n_pts, int cap, int batch, int width, int height,
+                           int border, float* out_pts, int* out_n, int* out_n2, hipStream_t st) {
+    ProfScope prof(VFE_K_COMPACT, st);
+    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, pts, status, n_pts, cap, width, height, border, out_pts, out_n, out_n2);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
@@ -174,7 +183,11 @@ AuxStream* vfe_aux_stream() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
     if (!made[dev]) {
         AuxStream a;
-        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        /* lowest priority: what runs here (the detector's image-only half) fills the chip beside the caller's stream, whose
+         * short dependent launches (the small pyramid levels in front of the tracker) must not queue behind its long waves */
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithPriority(&a.s, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
         pool[dev] = a; made[dev] = true;
@@ -303,17 +316,17 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
         if ((rc = gf_eig_phase(&next_levels[0], cap, quality, min_distance, cap, ws + L.gf_off, L.gf_bytes, aux->s))) return rc;
         VFE_HIP(hipEventRecord(aux->join, aux->s));
     }
-    if ((rc = vfe_dev_build_pyramid(next_levels, nlevels, stream))) return rc;
     /* the tracker takes each frame's points tile by tile (neighbours share cache lines and tend to converge together);
      * every point's result lands at its own index, so nothing downstream sees the order */
-    /* (not worth an extra launch when a handful of frames leaves most of the chip idle anyway) */
+    /* (not worth an extra launch when a handful of frames leaves most of the chip idle anyway; it needs the points only,
+     * so it goes in front of the pyramid instead of between the pyramid and the tracker) */
     unsigned short* order = (cap <= 65536 && (long long)batch * cap >= 16384) ? (unsigned short*)(ws + L.order_off) : nullptr;
     if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, order, st))) return rc;
+    if ((rc = vfe_dev_build_pyramid(next_levels, nlevels, stream))) return rc;
     if ((rc = klt_track_ordered(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
                                 win, max_iter, eps, min_eig_thr, 0, order, st))) return rc;
     if (reject && reject->f_threshold > 0 && (rc = fe_reject(reject, pts, next_pts, n_pts, cap, batch, w, h, status, st))) return rc;
-    if ((rc = vfe_dev_compact_tracks(next_pts, status, n_pts, cap, batch, w, h, 1, pts, n_pts, stream))) return rc;
-    if (n_tracked) VFE_HIP(hipMemcpyAsync(n_tracked, n_pts, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if ((rc = compact_tracks2(next_pts, status, n_pts, cap, batch, w, h, 1, pts, n_pts, n_tracked, st))) return rc;
     if (aux) {
         VFE_HIP(hipStreamWaitEvent(st, aux->join, 0));
         guard.joined = true;
