@@ -309,13 +309,18 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
     hipStream_t st = (hipStream_t)stream;
     AuxStream* aux = vfe_overlap_on() ? vfe_aux_stream() : nullptr;
     ForkGuard guard{nullptr, st, false};
-    if (aux) {
+    const EigBeside beside = eig_beside_policy(w, h, batch);
+    const bool fork_late = beside.after_pyramid;
+    auto fork_eig = [&]() -> int {
         VFE_HIP(hipEventRecord(aux->fork, st));
         VFE_HIP(hipStreamWaitEvent(aux->s, aux->fork, 0));
         guard.a = aux;
-        if ((rc = gf_eig_phase(&next_levels[0], cap, quality, min_distance, cap, ws + L.gf_off, L.gf_bytes, aux->s))) return rc;
+        int r = gf_eig_phase(&next_levels[0], cap, quality, min_distance, cap, ws + L.gf_off, L.gf_bytes, aux->s, beside.wgs_per_cu);
+        if (r) return r;
         VFE_HIP(hipEventRecord(aux->join, aux->s));
-    }
+        return VFE_OK;
+    };
+    if (aux && !fork_late && (rc = fork_eig())) return rc;
     /* the tracker takes each frame's points tile by tile (neighbours share cache lines and tend to converge together);
      * every point's result lands at its own index, so nothing downstream sees the order */
     /* (not worth an extra launch when a handful of frames leaves most of the chip idle anyway; it needs the points only,
@@ -323,6 +328,7 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
     unsigned short* order = (cap <= 65536 && (long long)batch * cap >= 16384) ? (unsigned short*)(ws + L.order_off) : nullptr;
     if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, order, st))) return rc;
     if ((rc = vfe_dev_build_pyramid(next_levels, nlevels, stream))) return rc;
+    if (aux && fork_late && (rc = fork_eig())) return rc;
     if ((rc = klt_track_ordered(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
                                 win, max_iter, eps, min_eig_thr, 0, order, st))) return rc;
     if (reject && reject->f_threshold > 0 && (rc = fe_reject(reject, pts, next_pts, n_pts, cap, batch, w, h, status, st))) return rc;

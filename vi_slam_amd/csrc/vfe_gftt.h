@@ -27,14 +27,28 @@ static inline EigGeom eig_geom(int w, int h, int batch) {
  * (as float bits, stride GF_CSTRIDE) and the candidate keys (score bits << 32 | y << 16 | x) of the 3x3
  * local maxima, GF_NSEG lists of seg_cap keys per frame with their counters after the maxima. */
 void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_count, u64* cand, u32 seg_cap,
-                     double quality, hipStream_t st);
+                     double quality, hipStream_t st, int wgs_per_cu = 0);
+
+/* How the eigenvalue pass should share the chip when it runs beside the tracker (front-end step).  Its workgroups hold a
+ * quarter of a SIMD's registers per wave; alone in front of the queue it fills every SIMD, and the tracker's waves (and the
+ * short pyramid launches in front of them) only start as its waves retire.  A long pass overlaps the whole tracker anyway;
+ * a shorter one is better held to 3 or 2 workgroups per CU (requested as spare LDS per workgroup), and a pass of a few
+ * thousand waves is better started behind the pyramid.  Measured at 1080p, 8 to 256 streams. */
+struct EigBeside { int wgs_per_cu; bool after_pyramid; };
+static inline EigBeside eig_beside_policy(int w, int h, int batch) {
+    const unsigned waves = eig_geom(w, h, batch).total;
+    if (waves >= 24000u) return {0, false};
+    if (waves >= 12000u) return {3, false};
+    if (waves >= 6000u) return {2, false};
+    return {0, true};
+}
 
 /* the two halves of vfe_dev_good_features: the first depends on the image only and may be enqueued on another
  * stream, the second needs the tracked points; same workspace, same parameters.  `append` (seed arrays with max_corners
  * slots per frame): the accepted corners are also written behind each frame's seeds and n_seeds grows by their number,
  * i.e. the selection does what vfe_dev_append_points would do next */
 int gf_eig_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance, int seed_cap, void* workspace,
-                 size_t workspace_bytes, hipStream_t st);
+                 size_t workspace_bytes, hipStream_t st, int wgs_per_cu = 0);
 int gf_select_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance,
                     const float* seeds_xy, const int* n_seeds, int seed_cap,
                     float* corners_xy, float* scores, int* counts, void* workspace, size_t workspace_bytes, hipStream_t st,

@@ -497,7 +497,7 @@ static int gf_check(const vfe_dimg* img, int max_corners, double quality, double
 /* first half of the detector: everything that depends on the image only (clears the counters and grid heads,
  * eigenvalue map + candidates).  May run on another stream than the second half. */
 int gf_eig_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance, int seed_cap, void* workspace,
-                 size_t workspace_bytes, hipStream_t st) {
+                 size_t workspace_bytes, hipStream_t st, int wgs_per_cu) {
     GfWs L;
     static const float dummy_c = 0.f; static const int dummy_n = 0;
     int rc = gf_check(img, max_corners, quality, min_distance, seed_cap ? &dummy_c : nullptr, seed_cap ? &dummy_n : nullptr, &seed_cap,
@@ -509,7 +509,7 @@ int gf_eig_phase(const vfe_dimg* img, int max_corners, double quality, double mi
     u32* cand_count = frame_max + (size_t)img->batch * GF_CSTRIDE;
     {
         ProfScope prof(VFE_K_GFTT_EIG, st);
-        gftt_eig_launch(to_dimg(img), nullptr, frame_max, cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality, st);
+        gftt_eig_launch(to_dimg(img), nullptr, frame_max, cand_count, (u64*)(ws + L.cand_off), L.seg_cap, quality, st, wgs_per_cu);
     }
     VFE_LAUNCH_CHECK();
     return VFE_OK;

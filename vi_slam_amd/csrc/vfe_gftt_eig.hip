@@ -61,8 +61,11 @@ __device__ static inline float min2(float a, float b) { /* no NaNs here: one ins
 #ifndef EV_WPB
 #define EV_WPB 4 /* waves per workgroup */
 #endif
+#ifndef EV_WPE
+#define EV_WPE 4 /* waves per SIMD the register budget is cut for */
+#endif
 template <bool WRITE_MAP, bool ALIGNED>
-__global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
+__global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(EV_WPE, EV_WPE))) void k_gftt_eig(DImg img, int strips_x, int band_h, int bands_y, unsigned total_work,
                                                   float* __restrict__ eigmap, u32* __restrict__ frame_max,
                                                   u32* __restrict__ cand_count, u64* __restrict__ cand, u32 seg_cap,
                                                   double quality, int band_mod, int band_sel) {
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_count, u64* cand, u32 seg_cap,
-                     double quality, hipStream_t st) {
+                     double quality, hipStream_t st, int wgs_per_cu) {
     const EigGeom g = eig_geom(d.w, d.h, d.batch);
     const unsigned nblk = (g.total + EV_WPB - 1) / EV_WPB;
     /* one item per wave: items are tens of microseconds long and few per wave, so handing them
@@ -397,11 +400,18 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
      * every wave starts with a maximum of 0 and all local maxima become candidates (tens of thousands on a 1080p
      * frame, of which a tenth survives the final threshold), which the selection kernel then pays for.  Such launches
      * run in two passes: an eighth of the bands first, the others with the maximum those found. */
+    /* at most wgs_per_cu workgroups per CU: each asks for so much LDS that one more does not fit, with half a share left
+     * for the kernels it runs beside (160 KB per CU) */
+    unsigned extra_lds = 0;
+    if (wgs_per_cu > 0 && wgs_per_cu < 4) {
+        const unsigned share = 163840u * 2u / (2u * (unsigned)wgs_per_cu + 1u), own = (unsigned)sizeof(u64) * EV_WPB * EV_STAGE + 512u;
+        extra_lds = (share - own) / 256u * 256u;
+    }
     const bool two_pass = g.total <= 4096u && g.bands_y >= 8;
     for (int pass = two_pass ? 1 : 0; pass >= 0; pass--) {
         const int mod = two_pass ? 8 : 0;
         if (aligned)
-            hipLaunchKernelGGL((k_gftt_eig<false, true>), grid, dim3(64 * EV_WPB), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
+            hipLaunchKernelGGL((k_gftt_eig<false, true>), grid, dim3(64 * EV_WPB), extra_lds, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
                                (float*)nullptr, frame_max, cand_count, cand, seg_cap, quality, mod, pass);
         else
             hipLaunchKernelGGL((k_gftt_eig<false, false>), grid, dim3(64 * EV_WPB), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
