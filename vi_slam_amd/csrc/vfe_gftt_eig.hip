@@ -390,7 +390,10 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
     /* one item per wave: items are tens of microseconds long and few per wave, so handing them
      * out through the dispatcher balances better than persistent waves with a fixed stride */
     dim3 grid(nblk < (1u << 22) ? nblk : (1u << 22));
-    const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0);
+    /* the dword-per-lane form addresses a frame as a raw buffer with 32-bit offsets: rows on dword boundaries, and a frame
+     * (plus one row) below 2 GB */
+    const bool aligned = ((uintptr_t)d.data % 4 == 0) && (d.pitch % 4 == 0) && (d.fstride % 4 == 0) &&
+                         (size_t)(d.h + 1) * (size_t)d.pitch < ((size_t)1 << 31);
     if (eigmap) {
         hipLaunchKernelGGL((k_gftt_eig<true, false>), grid, dim3(64 * EV_WPB), 0, st, d, g.strips_x, g.band_h, g.bands_y, g.total,
                            eigmap, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, 0u, 0.0, 0, 0);
