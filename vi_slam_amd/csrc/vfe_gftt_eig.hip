@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * EV_WPB) __attribute__((amdgpu_waves_per_eu(EV_
         const int y0 = byi * band_h, y1 = min(y0 + band_h, H);
         const uint8_t* ip = img.frame(b);
         /* 0x00020000: untyped 32-bit data; every access of a frame (plus the row past its end) lies inside the range */
-        const __amdgpu_buffer_rsrc_t frame_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ip, 0, (H + 1) * img.pitch, 0x00020000);
+        const __amdgpu_buffer_rsrc_t frame_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ip, 0, ALIGNED ? (H + 1) * img.pitch : 0, 0x00020000);
         u32 seen = 0;
         float prune = 0.f, wmax = 0.f;
         float prune_twice = -1.f; /* rows whose every min(sxx, syy) = 2 min(a, c) is <= this are skipped (negative: none) */
