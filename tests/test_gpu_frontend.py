@@ -70,6 +70,27 @@ def test_pyramid_levels_carry_reflect101_border(cuda, w, h):
             assert np.array_equal(full[i].cpu().numpy(), np.pad(inner, B, mode="reflect")), f"level {l} frame {i}"
 
 
+@pytest.mark.parametrize("w,h,levels", [(1920, 1080, 4), (752, 480, 4), (753, 479, 4), (750, 482, 5), (641, 363, 4), (1283, 721, 5),
+                                        (300, 280, 4), (2045, 1100, 6)])
+def test_pyramid_two_levels_per_launch(cuda, w, h, levels):
+    """From level 1 on the library forms two levels per launch: every level and its reflect-101 border equal the oracle's
+    pyrDown chain, at sizes whose halves are odd and even in turn, with blocks cut by the right and bottom rims."""
+    ims = [synth.noise(11, w, h), synth.scene(synth.BASE_SEED + 3, w, h, 1)]
+    lv = capi.build_pyramid(capi.alloc_pyramid(to_dev(ims, cuda), levels))
+    B = capi.LK_BORDER
+    for i, im in enumerate(ims):
+        ref = [im]
+        for _ in range(1, levels):
+            ref.append(ora.pyr_down(ref[-1]))
+        for l in range(1, levels):
+            t = lv[l]
+            b, lh, lw = t.shape
+            assert np.array_equal(t[i].cpu().numpy(), ref[l]), f"level {l} frame {i}"
+            if min(lh, lw) > B + 1:
+                full = t.as_strided((b, lh + 2 * B, lw + 2 * B), t.stride(), t.storage_offset() - B * t.stride(1) - B)
+                assert np.array_equal(full[i].cpu().numpy(), np.pad(ref[l], B, mode="reflect")), f"border of level {l} frame {i}"
+
+
 @pytest.mark.parametrize("padded", [True, False])
 def test_klt_border_points_padded_and_unpadded(cuda, padded):
     """Points whose windows overhang every side of the image, at every level: identical results with
