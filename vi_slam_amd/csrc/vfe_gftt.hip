@@ -61,22 +61,23 @@ __device__ static inline void st_agent(u32* p, u32 v) { __hip_atomic_store(p, v,
 /* v / cell for 0 <= v < 65536 */
 __device__ static inline int cell_of(int v, int cell, u32 magic) { return cell > 1 ? (int)__umulhi((u32)v, magic) : v; }
 
-/* inclusive suffix scan of 1024 values held one per thread; returns sum over threads >= tid */
+/* inclusive suffix scan of 1024 values held one per thread; returns sum over threads >= tid.  Inside a wave by shuffles,
+ * across the 16 waves through LDS: three barriers instead of a barrier per doubling step. */
 __device__ static inline u32 block_suffix_scan(u32 v, u32 (*buf)[SEL_THREADS]) {
-    const int tid = threadIdx.x;
-    int cur = 0;
-    buf[0][tid] = v;
-    __syncthreads();
-    for (int o = 1; o < SEL_THREADS; o <<= 1) {
-        u32 x = buf[cur][tid];
-        if (tid + o < SEL_THREADS) x += buf[cur][tid + o];
-        buf[cur ^ 1][tid] = x;
-        cur ^= 1;
-        __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 x = (u32)__shfl_down((int)v, o);
+        if (lane + o < 64) v += x;
     }
-    const u32 r = buf[cur][tid];
+    if (lane == 0) buf[0][wv] = v; /* the wave's total */
     __syncthreads();
-    return r;
+    u32 above = 0;
+#pragma unroll
+    for (int w = 1; w < SEL_THREADS / 64; w++)
+        if (w > wv) above += buf[0][w];
+    __syncthreads();
+    return v + above;
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
