@@ -32,14 +32,17 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
 /* How the eigenvalue pass should share the chip when it runs beside the tracker (front-end step).  Its workgroups hold a
  * quarter of a SIMD's registers per wave; alone in front of the queue it fills every SIMD, and the tracker's waves (and the
  * short pyramid launches in front of them) only start as its waves retire.  A long pass overlaps the whole tracker anyway;
- * a shorter one is better held to 3 or 2 workgroups per CU (requested as spare LDS per workgroup), and a pass of a few
- * thousand waves is better started behind the pyramid.  Measured at 1080p, 8 to 256 streams. */
+ * a shorter one is better held to 3 or 2 workgroups per CU (requested as spare LDS per workgroup), and a short one is
+ * better started behind the pyramid.  Measured on 1080p front-end steps, 8 to 256 streams (8640 strip rows per frame):
+ * 256 streams uncapped, 128 three workgroups per CU (+3 %), 64 two (+7 %), 32 and fewer behind the pyramid (+4 .. +14 %). */
 struct EigBeside { int wgs_per_cu; bool after_pyramid; };
+/* strip rows of a launch: the measure of its length (the number of waves is not -- the band height adapts to the batch) */
+static inline long long eig_strip_rows(int w, int h, int batch) { return (long long)div_up(w, EV_OUT) * h * batch; }
 static inline EigBeside eig_beside_policy(int w, int h, int batch) {
-    const unsigned waves = eig_geom(w, h, batch).total;
-    if (waves >= 24000u) return {0, false};
-    if (waves >= 12000u) return {3, false};
-    if (waves >= 6000u) return {2, false};
+    const long long rows = eig_strip_rows(w, h, batch); /* 8640 per 1080p frame */
+    if (rows >= 1600000) return {0, false};
+    if (rows >= 800000) return {3, false};
+    if (rows >= 400000) return {2, false};
     return {0, true};
 }
 

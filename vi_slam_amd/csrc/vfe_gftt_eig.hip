@@ -399,10 +399,13 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
                            eigmap, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, 0u, 0.0, 0, 0);
         return;
     }
-    /* Candidates are pruned against the frame maximum seen so far.  When the whole launch fits on the chip at once
-     * every wave starts with a maximum of 0 and all local maxima become candidates (tens of thousands on a 1080p
-     * frame, of which a tenth survives the final threshold), which the selection kernel then pays for.  Such launches
-     * run in two passes: an eighth of the bands first, the others with the maximum those found. */
+    /* Candidates are pruned against the frame maximum seen so far.  In a launch of which a large part fits on the chip at
+     * once those waves start with a maximum of 0 and all their local maxima become candidates (tens of thousands on a
+     * 1080p frame, of which a tenth survives the final threshold), which the selection kernel then pays for.  Such
+     * launches run in two passes: an eighth of the bands first, the others with the maximum those found.  Measured on
+     * 1080p front-end steps: the selection 86 -> 52 us at 8 streams, the step +1 % at 8, +5 % at 12, +2.5 % at 64 streams
+     * and +4 % at 32; nothing at 128, -1 % at 256 (their waves walk 64 rows and exchange the maximum on the way). */
+    const bool two_pass = eig_strip_rows(d.w, d.h, d.batch) < 800000 && g.bands_y >= 8;
     /* at most wgs_per_cu workgroups per CU: each asks for so much LDS that one more does not fit, with half a share left
      * for the kernels it runs beside (160 KB per CU) */
     unsigned extra_lds = 0;
@@ -410,7 +413,6 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
         const unsigned share = 163840u * 2u / (2u * (unsigned)wgs_per_cu + 1u), own = (unsigned)sizeof(u64) * EV_WPB * EV_STAGE + 512u;
         extra_lds = (share - own) / 256u * 256u;
     }
-    const bool two_pass = g.total <= 4096u && g.bands_y >= 8;
     for (int pass = two_pass ? 1 : 0; pass >= 0; pass--) {
         const int mod = two_pass ? 8 : 0;
         if (aligned)
