@@ -19,7 +19,7 @@ HOST_SRCS = $(wildcard $(HOST)/src/*.cpp)
 HOST_HDRS = $(wildcard $(HOST)/include/*/*.hpp) $(wildcard $(HOST)/include/*/*/*.hpp) include/vfe.h
 CPP_TESTS = $(patsubst tests/cpp/%.cpp,tests/cpp/bin/%,$(wildcard tests/cpp/*.cpp)) tests/cpp/bin/pc_client_video_callback
 
-HIP_TESTS = $(patsubst tests/hip/%.hip,tests/cpp/bin/%,$(wildcard tests/hip/*.hip)) tests/cpp/bin/valu_ceiling
+HIP_TESTS = $(patsubst tests/hip/%.hip,tests/cpp/bin/%,$(wildcard tests/hip/*.hip)) tests/cpp/bin/valu_ceiling tests/cpp/bin/hbm_stream
 
 all: $(LIBDIR)/libvfe_synth.so $(LIBDIR)/libvfe.so $(LIBDIR)/libvi_slam_amd.so $(CPP_TESTS) $(HIP_TESTS) oracle
 
@@ -63,6 +63,11 @@ tests/cpp/bin/%: tests/hip/%.hip $(HIP_HDRS)
 
 # measurement tool: VALU issue ceiling per instruction class (tools/valu_ceiling.hip)
 tests/cpp/bin/valu_ceiling: tools/valu_ceiling.hip
+	@mkdir -p tests/cpp/bin
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
+
+# measurement tool: what HBM delivers to plain streaming kernels (tools/hbm_stream.hip)
+tests/cpp/bin/hbm_stream: tools/hbm_stream.hip
 	@mkdir -p tests/cpp/bin
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
 

@@ -31,11 +31,19 @@ template <int N> using ic = std::integral_constant<int, N>;
 
 /* Source bytes IX0 .. IX0+15 of row iy.  Chunks entirely left of the image, or entirely right of
  * it when the width is a multiple of 16, are never read: the only bytes a neighbour would take
- * from them are reflections that the neighbour already holds (fixed up after the shuffle). */
+ * from them are reflections that the neighbour already holds (fixed up after the shuffle).
+ * `once`: the launch reads far more than the caches hold, so its loads carry the non-temporal hint
+ * (a 4 : 1 read / write stream moves ~10 % more bytes per second that way; the stores stay plain,
+ * the next level reads them back from cache). */
 template <bool W16>
-__device__ static inline uint4 pyr_load_row(const DImg& src, const uint8_t* sp, int iy, int IX0) {
+__device__ static inline uint4 pyr_load_row(const DImg& src, const uint8_t* sp, int iy, int IX0, bool once) {
     const uint8_t* row = sp + (size_t)reflect101(iy, src.h) * src.pitch;
-    if (IX0 >= 0 && IX0 + 15 < src.w) return *reinterpret_cast<const uint4*>(row + IX0);
+    if (IX0 >= 0 && IX0 + 15 < src.w) {
+        if (!once) return *reinterpret_cast<const uint4*>(row + IX0);
+        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(row + IX0));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
     uint32_t w[4] = {0, 0, 0, 0};
     if (!W16 && IX0 + 15 >= src.w && IX0 <= src.w + 16) {
 #pragma unroll
@@ -65,7 +73,8 @@ __device__ static inline void pyr_hsums(const uint4& c, u32 lw, u32 rb, u32 (&hp
 
 /* W16: the source width is a multiple of 16 (no lane straddles the right rim) */
 template <bool PAD, bool W16>
-__global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int strips_x, int band_h, int bands_y, unsigned total_work) {
+__global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int strips_x, int band_h, int bands_y, unsigned total_work, int read_once) {
+    const bool once = read_once != 0;
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
     const unsigned per_frame = (unsigned)(strips_x * bands_y);
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
         const int iy0 = 2 * oy0 - 2, iy1 = 2 * oy1; /* source rows iy0 .. iy1 */
         uint4 pre[PS_AHEAD];
 #pragma unroll
-        for (int k = 0; k < PS_AHEAD; k++) pre[k] = (iy0 + k <= iy1) ? pyr_load_row<W16>(src, sp, iy0 + k, IX0) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < PS_AHEAD; k++) pre[k] = (iy0 + k <= iy1) ? pyr_load_row<W16>(src, sp, iy0 + k, IX0, once) : make_uint4(0, 0, 0, 0);
         u32 A[3][4]; /* accumulators of three consecutive output rows, two 16-bit sums per dword */
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
             u32 hp[4];
             {   /* even row 2m */
                 const uint4 cur = pre[2 * ph];
-                if (2 * m + PS_AHEAD <= iy1) pre[2 * ph] = pyr_load_row<W16>(src, sp, 2 * m + PS_AHEAD, IX0);
+                if (2 * m + PS_AHEAD <= iy1) pre[2 * ph] = pyr_load_row<W16>(src, sp, 2 * m + PS_AHEAD, IX0, once);
                 u32 lw = (u32)__shfl_up((int)cur.w, 1), rb = (u32)__shfl_down((int)cur.x, 1) & 0xFFu;
                 /* at the image rim the halo bytes are reflections this lane already holds:
                  * bytes -2, -1 = bytes 2, 1; byte 16 = byte 14 */
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
             }
             {   /* odd row 2m+1 (not needed after the last output row; harmless then) */
                 const uint4 cur = pre[2 * ph + 1];
-                if (2 * m + 1 + PS_AHEAD <= iy1) pre[2 * ph + 1] = pyr_load_row<W16>(src, sp, 2 * m + 1 + PS_AHEAD, IX0);
+                if (2 * m + 1 + PS_AHEAD <= iy1) pre[2 * ph + 1] = pyr_load_row<W16>(src, sp, 2 * m + 1 + PS_AHEAD, IX0, once);
                 u32 lw = (u32)__shfl_up((int)cur.w, 1), rb = (u32)__shfl_down((int)cur.x, 1) & 0xFFu;
                 if (fix_l) lw = __builtin_amdgcn_perm(cur.x, cur.x, 0x01020c0cu);
                 if (fix_r) rb = (cur.w >> 16) & 0xFFu;
@@ -174,7 +183,9 @@ static bool vec_ok(const DImg& d, int align) {
 }
 bool pyr_down_stream_ok(const DImg& s, const DImg& d) { return vec_ok(s, 16) && vec_ok(d, 8); }
 
-typedef void (*pyr_kernel_t)(DImg, DImg, int, int, int, unsigned);
+typedef void (*pyr_kernel_t)(DImg, DImg, int, int, int, unsigned, int);
+
+#define PS_ONCE_BYTES (64ll << 20) /* a source this large is gone from the caches before anything reads it again */
 
 /* waves of `kern` that fit one SIMD (512 VGPRs each, at most 8 waves) */
 static int waves_per_simd(pyr_kernel_t kern) {
@@ -209,7 +220,8 @@ int pyr_down_stream_launch(const DImg& s, const DImg& d, hipStream_t st, bool* p
     const int bands_y = div_up(d.h, band_h);
     const unsigned total = (unsigned)(strips_x * bands_y * d.batch), nblk = (total + 3) / 4;
     const dim3 grid(nblk < (1u << 20) ? nblk : (1u << 20));
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, s, d, strips_x, band_h, bands_y, total);
+    const int read_once = (long long)s.w * s.h * s.batch >= PS_ONCE_BYTES;
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, s, d, strips_x, band_h, bands_y, total, read_once);
     VFE_LAUNCH_CHECK();
     *padded = pad;
     return VFE_OK;
