@@ -47,6 +47,8 @@ __device__ static inline unsigned pair_bytes(int k, unsigned a, unsigned b) {
 }
 /* (lo & 0xffff) | (hi << 16) */
 __device__ static inline unsigned pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
+/* (lo >> 16) | (hi & 0xffff0000) */
+__device__ static inline unsigned pack_hi16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x07060302u); }
 /* a.lo*w.lo + a.hi*w.hi + c on signed 16-bit halves.  Written as the three-address form: the
  * compiler's choice, the accumulating two-address form, costs a register copy per use whenever the
  * addend has to survive. */
@@ -155,7 +157,10 @@ __device__ static inline void piece_template(const unsigned (&w)[4][3], unsigned
         const unsigned p01 = pair_bytes(j & 3, w[0][j >> 2], w[1][j >> 2]);
         P12[j] = pair_bytes(j & 3, w[1][j >> 2], w[2][j >> 2]);
         const unsigned p23 = pair_bytes(j & 3, w[2][j >> 2], w[3][j >> 2]);
-        S[j] = (as_s2(p01) + as_s2(p23)) * (short)3 + as_s2(P12[j]) * (short)10;
+        /* the Scharr row sums and, below, the column sums carry a factor 4 (12 / 40 for 3 / 10; everything still fits
+         * 16 bits: 4 * 4080), so that the interpolated gradient's rounding shift becomes 16 and the result is the
+         * product's high half, which the pair-packing permute picks up directly */
+        S[j] = (as_s2(p01) + as_s2(p23)) * (short)12 + as_s2(P12[j]) * (short)40;
         D[j] = as_s2(p23) - as_s2(p01);
     }
     /* Scharr at window rows (y, y+1) packed, columns x .. x+NPX; the derivative image is zero
@@ -167,15 +172,15 @@ __device__ static inline void piece_template(const unsigned (&w)[4][3], unsigned
     for (int j = 0; j < NPX + 1; j++) {
         const unsigned m = !MASKED || (unsigned)(x + j) < (unsigned)IW ? mrow : 0u;
         vx[j] = as_u(S[j + 2] - S[j]);
-        vy[j] = as_u((D[j] + D[j + 2]) * (short)3 + D[j + 1] * (short)10);
+        vy[j] = as_u((D[j] + D[j + 2]) * (short)12 + D[j + 1] * (short)40);
         if (MASKED) { vx[j] &= m; vy[j] &= m; }
     }
     int ix[NPX + 1], iy[NPX + 1], iv[NPX + 1];
 #pragma unroll
     for (int k = 0; k < NPX; k++) {
         iv[k] = dot2(P12[k + 1], W0, dot2(P12[k + 2], W1, 1 << 8)) >> 9;
-        ix[k] = dot2(vx[k], W0, dot2(vx[k + 1], W1, 1 << 13)) >> 14;
-        iy[k] = dot2(vy[k], W0, dot2(vy[k + 1], W1, 1 << 13)) >> 14;
+        ix[k] = dot2(vx[k], W0, dot2(vx[k + 1], W1, 1 << 15)); /* gradient in bits 16..31 */
+        iy[k] = dot2(vy[k], W0, dot2(vy[k + 1], W1, 1 << 15));
         if (k >= 5 && k >= nvalid) { ix[k] = 0; iy[k] = 0; }
     }
     ix[NPX] = 0; iy[NPX] = 0; iv[NPX] = 0;
@@ -183,7 +188,7 @@ __device__ static inline void piece_template(const unsigned (&w)[4][3], unsigned
      * take two pixels per instruction as dot products of the packed pairs */
 #pragma unroll
     for (int k = 0; k < (NPX + 1) / 2; k++) {
-        const unsigned tx = pack16(ix[2 * k], ix[2 * k + 1]), ty = pack16(iy[2 * k], iy[2 * k + 1]);
+        const unsigned tx = pack_hi16(ix[2 * k], ix[2 * k + 1]), ty = pack_hi16(iy[2 * k], iy[2 * k + 1]);
         const unsigned tv = pack16(iv[2 * k], iv[2 * k + 1]);
         Tx[k] = tx; Ty[k] = ty;
         a11 = dot2(tx, tx, a11); a12 = dot2(tx, ty, a12); a22 = dot2(ty, ty, a22);
