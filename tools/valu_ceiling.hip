@@ -49,7 +49,9 @@ enum Cls {
     C_MAD_I24, C_MAX_U32, C_CVT_U32_F32, C_RNDNE, C_CVT_I32_F32, C_MAX_I32, C_ADD_I16, C_MAD_U16,
     /* 64-bit integer address arithmetic and double precision (register pairs) */
     C_MAD_U64_U32, C_MAD_I64_I32, C_LSHL_ADD_U64, C_CVT_F64_I32, C_CVT_F32_F64, C_CVT_F64_F32, C_FMA_F64, C_MUL_F64, C_ADD_F64,
-    C_PK_MOV, C_MOV_B64, C_COUNT
+    C_PK_MOV, C_MOV_B64,
+    /* sub-dword addressing: a shift whose 16-bit result lands in the upper half of the destination, the lower half kept */
+    C_LSHR_SDWA_W1, C_ADD_SDWA_W1SRC, C_COUNT
 };
 static const char* kNames[C_COUNT] = {
     "v_add_f32", "v_fma_f32", "v_max3_f32", "v_add_u32", "v_xor_b32", "v_and_or_b32", "v_lshlrev_b32", "v_min_u32", "v_med3_u32",
@@ -61,7 +63,7 @@ static const char* kNames[C_COUNT] = {
     "v_add3_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_mul_u32_u24", "v_alignbit_b32", "v_pk_sub_i16", "v_pk_lshrrev_b16", "v_sad_u8",
     "v_fmac_f32", "v_mad_i32_i24", "v_max_u32", "v_cvt_u32_f32", "v_rndne_f32", "v_cvt_i32_f32", "v_max_i32", "v_add_u16", "v_mad_u16",
     "v_mad_u64_u32", "v_mad_i64_i32", "v_lshl_add_u64", "v_cvt_f64_i32", "v_cvt_f32_f64", "v_cvt_f64_f32", "v_fma_f64", "v_mul_f64", "v_add_f64",
-    "v_pk_mov_b32", "v_mov_b64"};
+    "v_pk_mov_b32", "v_mov_b64", "v_lshrrev_b32_sdwa dst_sel:WORD_1 preserve", "v_add_u32_sdwa src1_sel:WORD_1"};
 
 template <int CLS>
 __global__ __launch_bounds__(1024) void k_issue(long long* __restrict__ stamps, uint32_t* __restrict__ sink, int trips, uint32_t seed) {
@@ -175,6 +177,8 @@ __global__ __launch_bounds__(1024) void k_issue(long long* __restrict__ stamps, 
         else if (CLS == C_ADD_F64) { OP64("v_add_f64 %0, %0, %1") }
         else if (CLS == C_PK_MOV) { OP64("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]") }
         else if (CLS == C_MOV_B64) { OP64("v_mov_b64 %0, %1") }
+        else if (CLS == C_LSHR_SDWA_W1) { OP32("v_lshrrev_b32_sdwa %0, 9, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD") }
+        else if (CLS == C_ADD_SDWA_W1SRC) { OP32("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1") }
     }
     const long long t1 = clock64();
     uint32_t acc = 0;

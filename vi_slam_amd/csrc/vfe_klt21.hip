@@ -49,6 +49,16 @@ __device__ static inline unsigned pair_bytes(int k, unsigned a, unsigned b) {
 __device__ static inline unsigned pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 /* (lo >> 16) | (hi & 0xffff0000) */
 __device__ static inline unsigned pack_hi16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x07060302u); }
+/* (lo >> 9) & 0xffff | (hi >> 9) << 16 for non-negative values below 2^25: the second shift writes its 16-bit result
+ * into the upper half of the destination and keeps the lower half (sub-dword addressing), which saves the permute that
+ * would join two shifted values.  A result written to half a register must not be read by the very next vector
+ * instruction; the compiler does not see into the statement, so the wait state is part of it. */
+__device__ static inline unsigned pack_shr9(int lo, int hi) {
+    unsigned d = (unsigned)lo >> 9;
+    asm("v_lshrrev_b32_sdwa %0, 9, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\ts_nop 0"
+        : "+v"(d) : "v"(hi));
+    return d;
+}
 /* a.lo*w.lo + a.hi*w.hi + c on signed 16-bit halves.  Written as the three-address form: the
  * compiler's choice, the accumulating two-address form, costs a register copy per use whenever the
  * addend has to survive. */
@@ -178,7 +188,7 @@ __device__ static inline void piece_template(const unsigned (&w)[4][3], unsigned
     int ix[NPX + 1], iy[NPX + 1], iv[NPX + 1];
 #pragma unroll
     for (int k = 0; k < NPX; k++) {
-        iv[k] = dot2(P12[k + 1], W0, dot2(P12[k + 2], W1, 1 << 8)) >> 9;
+        iv[k] = dot2(P12[k + 1], W0, dot2(P12[k + 2], W1, 1 << 8)); /* intensity x 32 in bits 9.. */
         ix[k] = dot2(vx[k], W0, dot2(vx[k + 1], W1, 1 << 15)); /* gradient in bits 16..31 */
         iy[k] = dot2(vy[k], W0, dot2(vy[k + 1], W1, 1 << 15));
         if (k >= 5 && k >= nvalid) { ix[k] = 0; iy[k] = 0; }
@@ -189,28 +199,28 @@ __device__ static inline void piece_template(const unsigned (&w)[4][3], unsigned
 #pragma unroll
     for (int k = 0; k < (NPX + 1) / 2; k++) {
         const unsigned tx = pack_hi16(ix[2 * k], ix[2 * k + 1]), ty = pack_hi16(iy[2 * k], iy[2 * k + 1]);
-        const unsigned tv = pack16(iv[2 * k], iv[2 * k + 1]);
+        const unsigned tv = pack_shr9(iv[2 * k], iv[2 * k + 1]);
         Tx[k] = tx; Ty[k] = ty;
         a11 = dot2(tx, tx, a11); a12 = dot2(tx, ty, a12); a22 = dot2(ty, ty, a22);
         c1 = dot2(tv, tx, c1); c2 = dot2(tv, ty, c2);
     }
 }
 
-/* Bilinear-interpolated intensities (times 32) of a piece.  w[i] holds image rows y, y+1, bytes
- * x .. x+11. */
+/* Bilinear-interpolated intensities of a piece before the rounding shift (intensity times 32 = val >> 9; the rounding
+ * constant is already added).  w[i] holds image rows y, y+1, bytes x .. x+11. */
 template <int NPX>
 __device__ static inline void piece_values(const unsigned (&w)[2][3], unsigned W0, unsigned W1, int* val) {
     unsigned Q[NPX + 1];
 #pragma unroll
     for (int k = 0; k < NPX + 1; k++) Q[k] = pair_bytes(k & 3, w[0][k >> 2], w[1][k >> 2]);
 #pragma unroll
-    for (int k = 0; k < NPX; k++) val[k] = dot2(Q[k], W0, dot2(Q[k + 1], W1, 1 << 8)) >> 9;
+    for (int k = 0; k < NPX; k++) val[k] = dot2(Q[k], W0, dot2(Q[k + 1], W1, 1 << 8));
 }
 template <int NPX>
 __device__ static inline void piece_mismatch(const int* val, const unsigned* Tx, const unsigned* Ty, int& b1, int& b2) {
 #pragma unroll
     for (int k = 0; k < (NPX + 1) / 2; k++) {
-        const unsigned d = pack16(val[2 * k], 2 * k + 1 < NPX ? val[2 * k + 1] : 0);
+        const unsigned d = 2 * k + 1 < NPX ? pack_shr9(val[2 * k], val[2 * k + 1]) : (unsigned)val[2 * k] >> 9;
         b1 = dot2(d, Tx[k], b1); b2 = dot2(d, Ty[k], b2);
     }
 }
@@ -244,7 +254,7 @@ __device__ static inline int piece_residual(const unsigned* areaJ, const unsigne
     piece_values<NPX>(w, Wt0, Wt1, vi);
     int es = 0;
 #pragma unroll
-    for (int k = 0; k < NPX; k++) es += (k >= 5 && k >= nvalid) ? 0 : abs(vj[k] - vi[k]);
+    for (int k = 0; k < NPX; k++) es += (k >= 5 && k >= nvalid) ? 0 : abs((vj[k] >> 9) - (vi[k] >> 9));
     __builtin_amdgcn_sched_barrier(0);
     return es;
 }
