@@ -310,7 +310,7 @@ class FrontendLeg:
         import torch
         from vi_slam_amd import capi
         self.torch, self.capi = torch, capi
-        self.frames = [f[:batch] for f in frames]
+        self.frames = [f[:batch] if f is not None else None for f in frames]
         self.B = batch
         self.pyr = [capi.alloc_pyramid(self.frames[0], LEVELS), capi.alloc_pyramid(self.frames[0], LEVELS)]
         self.fe = capi.FrontendStep(batch, H, W, NFEAT, LEVELS, WIN, quality=QUALITY, min_distance=MIN_DIST, device=dev)
@@ -356,6 +356,49 @@ class FrontendLeg:
         torch.cuda.synchronize()
         self.fe.n_pts.copy_(saved)
         return e0.elapsed_time(e1) / reps
+
+
+class UploadLeg(FrontendLeg):
+    """The same step with every frame arriving from pinned host memory (the H2D-inclusive figure of configs[3]): three
+    device frame buffers per stream, the upload of frame i + 1 on a copy stream beside the step on frame i (the step reads
+    frame i - 1 as the previous image, so a buffer is free again one step later)."""
+
+    def __init__(self, host_frames, batch, loss, dev):
+        import torch
+        from vi_slam_amd import capi
+        # rows packed (pitch = width, 16-byte aligned at 1920): nothing but pixels crosses the link
+        self.bufs = [torch.empty((batch, H, W), dtype=torch.uint8, device=dev) for _ in range(3)]
+        self.pinned = [torch.from_numpy(np.ascontiguousarray(hf[:batch])).pin_memory() for hf in host_frames]
+        self.bufs[0].copy_(self.pinned[0])
+        super().__init__([self.bufs[0]] + [None] * (len(host_frames) - 1), batch, loss, dev)
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.up_done = [torch.cuda.Event() for _ in range(3)]
+        self.step_done = torch.cuda.Event()
+        self.step_done.record()
+        self.upload(1)
+        self.bytes_per_step = self.pinned[0].numel()
+
+    def upload(self, i):
+        """Frame i of the visiting order into buffer i % 3, once the step that last read that buffer is done."""
+        torch = self.torch
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.step_done)
+            self.bufs[i % 3].copy_(self.pinned[self.order[(i - 1) % len(self.order)]], non_blocking=True)
+            self.up_done[i % 3].record(self.copy_stream)
+
+    def step(self):
+        torch = self.torch
+        i = self.pos + 1
+        torch.cuda.current_stream().wait_event(self.up_done[i % 3])
+        self.upload(i + 1)  # waits for step i - 1 only: runs beside step i
+        nxt = self.cur ^ 1
+        self.pyr[nxt][0] = self.bufs[i % 3]
+        self.fe.step(self.pyr[self.cur], self.pyr[nxt])
+        if self.keep_num < self.keep_den:
+            self.drop_tracks()
+        self.step_done.record()
+        self.cur = nxt
+        self.pos += 1
 
 
 def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg, overlap):
@@ -640,6 +683,19 @@ def main():
                                 "streams_per_gpu": nb, "steps": steps64, "ms_per_step": el / steps64 * 1e3,
                                 "frac_of_hbm_roofline": 64 * steps64 / el / world * BYTES_FRAME / (HBM_PEAK_GBS * 1e9),
                                 "roofline": rf, "kernels": ker, "kernel_timing": kn, "tracks": trk}
+            log("streams64 leg, frames uploaded from pinned host memory every step")
+            U = UploadLeg(host, nb, args.loss, dev)
+            capi.set_overlap(overlap)
+            steps_up = max(20, args.steps // 4)
+            el_up, _ = timed(rk, U.step, steps_up, max(3, args.warmup // 2))
+            out["streams64"]["h2d_inclusive"] = {
+                "value": 64 * steps_up / el_up, "unit": "frames/s", "steps": steps_up, "ms_per_step": el_up / steps_up * 1e3,
+                "upload_bytes_per_step_per_gpu": U.bytes_per_step,
+                "upload_GBs_per_gpu": U.bytes_per_step * steps_up / el_up / 1e9,
+                "what": "the same step with every frame copied from pinned host memory first (packed rows, one "
+                        "contiguous copy per batch on a copy stream, three frame buffers per stream so that the upload of the next "
+                        "frame runs beside the step); never the headline value"}
+            del U
     if "orb_match" in legs:
         ob = min(args.orb_batch, B)
         log("orb_match leg")
