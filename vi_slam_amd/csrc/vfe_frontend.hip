@@ -262,7 +262,7 @@ extern "C" int vfe_dev_frontend_step_fast(const vfe_dimg* prev_levels, const vfe
     hipStream_t st = (hipStream_t)stream;
     if ((rc = vfe_dev_build_pyramid(next_levels, nlevels, stream))) return rc;
     unsigned short* order = (cap <= 65536 && (long long)batch * cap >= 16384) ? (unsigned short*)(ws + L.order_off) : nullptr;
-    if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, order, st))) return rc;
+    if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, nlevels, order, st))) return rc;
     if ((rc = klt_track_ordered(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
                                 win, max_iter, eps, min_eig_thr, 0, order, st))) return rc;
     if ((rc = vfe_dev_compact_tracks(next_pts, status, n_pts, cap, batch, w, h, 1, pts, n_pts, stream))) return rc;
@@ -326,7 +326,7 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
     /* (not worth an extra launch when a handful of frames leaves most of the chip idle anyway; it needs the points only,
      * so it goes in front of the pyramid instead of between the pyramid and the tracker) */
     unsigned short* order = (cap <= 65536 && (long long)batch * cap >= 16384) ? (unsigned short*)(ws + L.order_off) : nullptr;
-    if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, order, st))) return rc;
+    if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, nlevels, order, st))) return rc;
     if ((rc = vfe_dev_build_pyramid(next_levels, nlevels, stream))) return rc;
     if (aux && fork_late && (rc = fork_eig())) return rc;
     if ((rc = klt_track_ordered(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,

@@ -42,6 +42,6 @@ int klt_track_ordered(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, 
                       const float* prev_pts, const int* n_pts, int pts_cap, float* next_pts, uint8_t* status, float* err,
                       int win, int max_iter, double eps, double min_eig_thr, int use_initial_flow,
                       const unsigned short* order, hipStream_t stream);
-/* fills order[batch][cap] with every frame's points sorted by image tile (counting sort, one workgroup per frame);
- * cap <= 65536 */
-int klt_order_launch(const float* pts, const int* n_pts, int cap, int batch, int w, int h, unsigned short* order, hipStream_t stream);
+/* fills order[batch][cap] with every frame's points sorted by rim class (the coarsest of the `nlevels` pyramid levels at
+ * which the point's window overhangs the level), then by image tile (counting sort, one workgroup per frame); cap <= 65536 */
+int klt_order_launch(const float* pts, const int* n_pts, int cap, int batch, int w, int h, int nlevels, unsigned short* order, hipStream_t stream);

@@ -180,18 +180,26 @@ __global__ __launch_bounds__(64) void k_klt(KltParams p) {
 
 #define ORD_CELLS 4096
 __global__ __launch_bounds__(256) void k_klt_order(const float* __restrict__ pts, const int* __restrict__ n_pts, int cap, int w, int h,
-                                                   int shift, int gx, int cells, unsigned short* __restrict__ order) {
+                                                   int shift, int gx, int tiles, int nlevels, unsigned short* __restrict__ order) {
     __shared__ unsigned s_cnt[ORD_CELLS];
     __shared__ unsigned s_scan[2][256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = n_pts ? max(0, min(n_pts[b], cap)) : cap;
     const float* p = pts + (size_t)b * cap * 2;
     unsigned short* o = order + (size_t)b * cap;
+    const int cells = tiles * (nlevels + 1);
     for (int c = tid; c < cells; c += 256) s_cnt[c] = 0;
     __syncthreads();
+    /* Sort key: first the coarsest pyramid level at which the point's 21 x 21 window still overhangs the level (a window
+     * lies inside level l when the point keeps 11 * 2^l pixels from the rim; class nlevels = inside everywhere), then the
+     * tile.  A wave of four points takes the tracker's costlier masked template at a level as soon as one of its windows
+     * overhangs there; with the rim points of a frame next to each other only their waves do. */
     auto cell_of_point = [&](int i) {
         const int x = min(max((int)p[2 * i], 0), w - 1), y = min(max((int)p[2 * i + 1], 0), h - 1);
-        return (y >> shift) * gx + (x >> shift);
+        const int rim = min(min(x, w - 1 - x), min(y, h - 1 - y));
+        int cls = 0;
+        while (cls < nlevels && rim >= (11 << cls)) cls++;
+        return cls * tiles + (y >> shift) * gx + (x >> shift);
     };
     for (int i = tid; i < n; i += 256) atomicAdd(&s_cnt[cell_of_point(i)], 1u);
     __syncthreads();
@@ -224,13 +232,14 @@ __global__ __launch_bounds__(256) void k_klt_order(const float* __restrict__ pts
     for (int i = tid; i < n; i += 256) o[atomicAdd(&s_cnt[cell_of_point(i)], 1u)] = (unsigned short)i;
 }
 
-int klt_order_launch(const float* pts, const int* n_pts, int cap, int batch, int w, int h, unsigned short* order, hipStream_t stream) {
-    VFE_REQUIRE(pts && order && cap > 0 && cap <= 65536 && batch > 0 && w > 0 && h > 0, "bad arguments for the point order");
+int klt_order_launch(const float* pts, const int* n_pts, int cap, int batch, int w, int h, int nlevels, unsigned short* order, hipStream_t stream) {
+    VFE_REQUIRE(pts && order && cap > 0 && cap <= 65536 && batch > 0 && w > 0 && h > 0 && nlevels >= 1 && nlevels <= KLT_MAX_LEVELS,
+                "bad arguments for the point order");
     int shift = 6; /* 64-pixel tiles, coarser for very large frames */
-    while ((long long)((w >> shift) + 1) * ((h >> shift) + 1) > ORD_CELLS) shift++;
-    const int gx = (w >> shift) + 1, cells = gx * ((h >> shift) + 1);
+    while ((long long)((w >> shift) + 1) * ((h >> shift) + 1) * (nlevels + 1) > ORD_CELLS) shift++;
+    const int gx = (w >> shift) + 1, tiles = gx * ((h >> shift) + 1);
     ProfScope prof(VFE_K_MISC, stream);
-    hipLaunchKernelGGL(k_klt_order, dim3(batch), dim3(256), 0, stream, pts, n_pts, cap, w, h, shift, gx, cells, order);
+    hipLaunchKernelGGL(k_klt_order, dim3(batch), dim3(256), 0, stream, pts, n_pts, cap, w, h, shift, gx, tiles, nlevels, order);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }

@@ -45,8 +45,6 @@ __device__ static inline unsigned as_u(s16x2 v) { return __builtin_bit_cast(unsi
 __device__ static inline unsigned pair_bytes(int k, unsigned a, unsigned b) {
     return __builtin_amdgcn_perm(b, a, 0x0c040c00u + (unsigned)k * 0x00010001u);
 }
-/* (lo & 0xffff) | (hi << 16) */
-__device__ static inline unsigned pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 /* (lo >> 16) | (hi & 0xffff0000) */
 __device__ static inline unsigned pack_hi16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x07060302u); }
 /* (lo >> 9) & 0xffff | (hi >> 9) << 16 for non-negative values below 2^25: the second shift writes its 16-bit result
