@@ -106,7 +106,7 @@ extern "C" void vfe_destroy(vfe_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int s = 0; s < 2; s++)
         for (int l = 0; l < CTX_MAX_LK_LEVELS; l++) (void)hipFree(c->pyr[s][l]);
-    void* bufs[] = {c->bgr, c->pts, c->next_pts, c->corners, c->err, c->status, c->n_pts, c->n_tracked, c->counts,
+    void* bufs[] = {c->bgr, c->pts, c->next_pts, c->corners, c->err, c->status, c->n_pts, c->counts,
                     c->ws, c->orb_kps, c->orb_desc, c->mws, c->eq_hist};
     for (void* p : bufs) (void)hipFree(p);
     (void)hipFree(c->f_ws);
@@ -176,7 +176,7 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
     CTX_TRY(hipMalloc((void**)&c->err, N * sizeof(float)));
     CTX_TRY(hipMalloc((void**)&c->status, N));
     CTX_TRY(hipMalloc((void**)&c->n_pts, 256));
-    CTX_TRY(hipMalloc((void**)&c->n_tracked, 256));
+    c->n_tracked = c->n_pts + 1; /* next to each other: one copy brings both counts back */
     CTX_TRY(hipMalloc((void**)&c->counts, 256));
     CTX_TRY(hipMemsetAsync(c->n_pts, 0, 256, c->stream));
     size_t ws = vfe_frontend_workspace(cfg->max_width, cfg->max_height, 1, cfg->max_features);
@@ -437,8 +437,7 @@ extern "C" int vfe_process_frame(vfe_ctx* c, const uint8_t* data, int rows, int 
                                                c->cfg.win_size, 30, 0.01, 1e-4, c->ws, c->ws_bytes, c->f_thr > 0 ? &rj : nullptr,
                                                c->stream))) return rc;
     }
-    VFE_HIP(hipMemcpyAsync(&c->h_small[0], c->n_pts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    VFE_HIP(hipMemcpyAsync(&c->h_small[1], c->n_tracked, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VFE_HIP(hipMemcpyAsync(&c->h_small[0], c->n_pts, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream)); /* n_pts, n_tracked */
     VFE_HIP(hipStreamSynchronize(c->stream));
     h_n[0] = c->h_small[0]; h_n[1] = c->h_small[1];
     c->cur = nxt; c->have_prev = 1; c->w = cols; c->h = rows;
