@@ -78,13 +78,18 @@ static int ctx_upload(vfe_ctx* c, int slot, const uint8_t* data, int rows, int c
     uint8_t* hs = c->h_stage[slot & 1];
     const size_t row_bytes = (size_t)cols * channels;
     const size_t dpitch = channels == 1 ? (size_t)c->pitch[0] : (size_t)c->cfg.max_width * 3;
-    if (step == dpitch) memcpy(hs, data, dpitch * (size_t)(rows - 1) + row_bytes);
-    else for (int y = 0; y < rows; y++) memcpy(hs + (size_t)y * dpitch, data + (size_t)y * step, row_bytes);
+    /* in bands of rows: the copy engine moves a band while the host repacks the next one */
+    uint8_t* dst = channels == 1 ? c->pyr[slot][0] : c->bgr;
     const size_t total = dpitch * (size_t)(rows - 1) + row_bytes;
-    if (channels == 1) {
-        VFE_HIP(hipMemcpyAsync(c->pyr[slot][0], hs, total, hipMemcpyHostToDevice, c->stream));
-    } else {
-        VFE_HIP(hipMemcpyAsync(c->bgr, hs, total, hipMemcpyHostToDevice, c->stream));
+    const int nbands = total >= (1u << 20) ? 4 : total >= (1u << 18) ? 2 : 1;
+    for (int k = 0; k < nbands; k++) {
+        const int r0 = (int)((long long)rows * k / nbands), r1 = (int)((long long)rows * (k + 1) / nbands);
+        const size_t off = (size_t)r0 * dpitch, bytes = dpitch * (size_t)(r1 - r0 - 1) + row_bytes;
+        if (step == dpitch) memcpy(hs + off, data + off, bytes);
+        else for (int y = r0; y < r1; y++) memcpy(hs + (size_t)y * dpitch, data + (size_t)y * step, row_bytes);
+        VFE_HIP(hipMemcpyAsync(dst + off, hs + off, bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    if (channels != 1) {
         vfe_dimg s; s.data = c->bgr; s.width = cols; s.height = rows; s.pitch = (int)dpitch; s.batch = 1; s.frame_stride = dpitch * rows; s.border = 0;
         vfe_dimg g = ctx_level(c, slot, 0, cols, rows);
         int rc = vfe_dev_bgr2gray(&s, &g, c->stream);
