@@ -16,10 +16,14 @@ except FileNotFoundError:
 ev.sort()
 klt = [i for i, e in enumerate(ev) if "k_klt21" in e[2]]
 i = klt[len(klt) // 2]
-# back up to the upload that starts this call
+# back up to the first upload band of this call (the frame arrives in a few consecutive host-to-device copies)
+def is_up(e):
+    return e[2].startswith("COPY") and "HOST_TO_DEVICE" in e[2] and e[1] - e[0] > 8000
 j = i
-while j > 0 and not (ev[j][2].startswith("COPY") and "HOST_TO_DEVICE" in ev[j][2] and ev[j][1] - ev[j][0] > 20000):
+while j > 0 and not is_up(ev[j]):
+    j -= 1
+while j > 0 and is_up(ev[j - 1]):
     j -= 1
 t0 = ev[j][0]
-for s, e, n in ev[j:j + 22]:
+for s, e, n in ev[j:j + 28]:
     print(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:7.1f} us  {n}")
