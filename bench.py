@@ -425,7 +425,35 @@ def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg, over
                                    "what": "n_pts <- floor(n_pts * keep): two element-wise torch kernels per step, timed apart"}
     tracked = float(L.fe.n_tracked.float().mean().item())
     points = float(L.fe.n_pts.float().mean().item())
-    return elapsed, kernels, roofline_for(kernels, counters, leg, batch), {"mean_tracked": tracked, "mean_points": points}, note
+    tracks = {"mean_tracked": tracked, "mean_points": points}
+    if leg == "main":
+        tracks["klt_with_err_output"] = klt_full_call_ms(L)
+    return elapsed, kernels, roofline_for(kernels, counters, leg, batch), tracks, note
+
+
+def klt_full_call_ms(L, reps=10):
+    """The tracker as the whole cv::calcOpticalFlowPyrLK call, i.e. with the per-point residual (`err`) that the front-end
+    step never reads and therefore skips: the leg's current pyramids and points, caller order, results discarded."""
+    torch, capi = L.torch, L.capi
+    prev, nxt = L.pyr[L.cur ^ 1], L.pyr[L.cur]
+    pts, n = L.fe.pts, L.fe.n_pts
+    out = [torch.zeros_like(pts), torch.zeros(pts.shape[:2], dtype=torch.uint8, device=pts.device),
+           torch.zeros(pts.shape[:2], dtype=torch.float32, device=pts.device)]
+    res = {}
+    for name, err in (("without_err_ms", False), ("with_err_ms", True)):
+        call = (lambda: capi.klt_track(prev, nxt, pts, n, out[0], out[1], out[2], win=WIN)) if err else \
+               (lambda: capi.klt_track_no_err(prev, nxt, pts, n, out[0], out[1], win=WIN))
+        call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / reps
+    res["what"] = ("vfe_dev_klt_track on the leg's pyramids and points in caller order (no tile / rim ordering), with and "
+                   "without the err output of calcOpticalFlowPyrLK; the front-end step runs the form without")
+    return res
 
 
 def orb_level_pixels():

@@ -269,6 +269,16 @@ def klt_track(prev_levels, next_levels, prev_pts, n_pts=None, next_pts=None, sta
     return next_pts, status, err
 
 
+def klt_track_no_err(prev_levels, next_levels, prev_pts, n_pts, next_pts, status, win=21, max_iter=30, eps=0.01, min_eig_thr=1e-4):
+    """vfe_dev_klt_track without the err output (NULL): the tracker then skips the residual pass at the final position."""
+    n = len(prev_levels)
+    pa = (DImg * n)(*[dimg(t) for t in prev_levels])
+    na = (DImg * n)(*[dimg(t) for t in next_levels])
+    check(lib().vfe_dev_klt_track(pa, na, n, _ptr(prev_pts), _ptr(n_pts), prev_pts.shape[1], _ptr(next_pts), _ptr(status),
+                                  None, win, max_iter, eps, min_eig_thr, 0, _stream()))
+    return next_pts, status
+
+
 def klt_track_bidir(prev_levels, next_levels, prev_pts, n_pts=None, max_recovered_dist2=0.04,
                     win=21, max_iter=30, eps=0.01, min_eig_thr=1e-4):
     """Forward track + backward check; returns (next_pts, status, err, back_pts)."""
