@@ -153,15 +153,24 @@ __device__ static inline void read_piece(const unsigned* area, int row, int dw, 
  * Tx/Ty receive the bilinear-interpolated Scharr gradients packed in pairs of pixels (zero
  * outside the window); the Gram sums and the sums I*gx, I*gy are accumulated.  MASKED is the
  * variant for windows that overhang the image. */
-template <int NPX, bool MASKED>
+/* what a piece hands to the next piece of the same window row, which starts 8 columns on: the three columns they share
+ * (row sums and differences, the middle row pairs of the last two) and the Scharr values of the first shared column */
+struct PieceCarry { s16x2 S[3], D[3]; unsigned P[2], vx, vy; };
+template <int NPX, bool MASKED, bool CARRY_IN, bool CARRY_OUT>
 __device__ static inline void piece_template(const unsigned (&w)[4][3], unsigned W0, unsigned W1,
                                              bool interior, int x, int y, int IW, int IH, int nvalid,
-                                             unsigned* Tx, unsigned* Ty, int& a11, int& a12, int& a22, int& c1, int& c2) {
+                                             unsigned* Tx, unsigned* Ty, int& a11, int& a12, int& a22, int& c1, int& c2,
+                                             PieceCarry& carry) {
     constexpr int NC = NPX + 3;
     unsigned P12[NC];
     s16x2 S[NC], D[NC];
 #pragma unroll
     for (int j = 0; j < NC; j++) {
+        if (CARRY_IN && j < 3) {
+            S[j] = carry.S[j]; D[j] = carry.D[j];
+            P12[j] = j ? carry.P[j - 1] : 0u;
+            continue;
+        }
         const unsigned p01 = pair_bytes(j & 3, w[0][j >> 2], w[1][j >> 2]);
         P12[j] = pair_bytes(j & 3, w[1][j >> 2], w[2][j >> 2]);
         const unsigned p23 = pair_bytes(j & 3, w[2][j >> 2], w[3][j >> 2]);
@@ -178,10 +187,18 @@ __device__ static inline void piece_template(const unsigned (&w)[4][3], unsigned
     unsigned vx[NPX + 1], vy[NPX + 1];
 #pragma unroll
     for (int j = 0; j < NPX + 1; j++) {
+        if (CARRY_IN && j == 0) { vx[0] = carry.vx; vy[0] = carry.vy; continue; }
         const unsigned m = !MASKED || (unsigned)(x + j) < (unsigned)IW ? mrow : 0u;
         vx[j] = as_u(S[j + 2] - S[j]);
         vy[j] = as_u((D[j] + D[j + 2]) * (short)12 + D[j + 1] * (short)40);
         if (MASKED) { vx[j] &= m; vy[j] &= m; }
+    }
+    if (CARRY_OUT) {
+        static_assert(!CARRY_OUT || NPX == 8, "the next piece starts 8 columns on");
+#pragma unroll
+        for (int j = 0; j < 3; j++) { carry.S[j] = S[NPX + j]; carry.D[j] = D[NPX + j]; }
+        carry.P[0] = P12[NPX + 1]; carry.P[1] = P12[NPX + 2];
+        carry.vx = vx[NPX]; carry.vy = vy[NPX];
     }
     int ix[NPX + 1], iy[NPX + 1], iv[NPX + 1];
 #pragma unroll
@@ -351,19 +368,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
                 const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < I.w && ipy + win < I.h;
                 int b11 = 0, b12 = 0, b22 = 0, d1 = 0, d2 = 0;
                 unsigned w[4][3];
+                PieceCarry carry;
                 /* wave-uniform choice: the masked variant only when some point of the wave needs it */
 #define KLT_TEMPLATE_PIECES(MASKED)                                                                                        \
     read_piece<4>(area, sub, 0, w);                                                                                        \
-    piece_template<8, MASKED>(w, Wt0, Wt1, interior, ipx, ipy + sub, I.w, I.h, 8, TxA, TyA, a11, a12, a22, c1, c2);         \
+    piece_template<8, MASKED, false, true>(w, Wt0, Wt1, interior, ipx, ipy + sub, I.w, I.h, 8, TxA, TyA, a11, a12, a22, c1, c2, carry); \
     __builtin_amdgcn_sched_barrier(0);                                                                                     \
     read_piece<4>(area, sub, 2, w);                                                                                        \
-    piece_template<8, MASKED>(w, Wt0, Wt1, interior, ipx + 8, ipy + sub, I.w, I.h, 8, TxA + 4, TyA + 4, a11, a12, a22, c1, c2); \
+    piece_template<8, MASKED, true, true>(w, Wt0, Wt1, interior, ipx + 8, ipy + sub, I.w, I.h, 8, TxA + 4, TyA + 4, a11, a12, a22, c1, c2, carry); \
     __builtin_amdgcn_sched_barrier(0);                                                                                     \
     read_piece<4>(area, sub, 4, w);                                                                                        \
-    piece_template<5, MASKED>(w, Wt0, Wt1, interior, ipx + 16, ipy + sub, I.w, I.h, 5, TxA + 8, TyA + 8, a11, a12, a22, c1, c2); \
+    piece_template<5, MASKED, true, false>(w, Wt0, Wt1, interior, ipx + 16, ipy + sub, I.w, I.h, 5, TxA + 8, TyA + 8, a11, a12, a22, c1, c2, carry); \
     __builtin_amdgcn_sched_barrier(0);                                                                                     \
     read_piece<4>(area, L.rB, L.cB / 4, w);                                                                                \
-    piece_template<8, MASKED>(w, Wt0, Wt1, interior, ipx + L.cB, ipy + L.rB, I.w, I.h, L.nB, TxB, TyB, b11, b12, b22, d1, d2); \
+    piece_template<8, MASKED, false, false>(w, Wt0, Wt1, interior, ipx + L.cB, ipy + L.rB, I.w, I.h, L.nB, TxB, TyB, b11, b12, b22, d1, d2, carry); \
     __builtin_amdgcn_sched_barrier(0);
                 if (__builtin_amdgcn_ballot_w64(!interior) != 0) { KLT_TEMPLATE_PIECES(true) } else { KLT_TEMPLATE_PIECES(false) }
 #undef KLT_TEMPLATE_PIECES
