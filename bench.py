@@ -426,7 +426,7 @@ def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg, over
     tracked = float(L.fe.n_tracked.float().mean().item())
     points = float(L.fe.n_pts.float().mean().item())
     tracks = {"mean_tracked": tracked, "mean_points": points}
-    if leg == "main":
+    if leg == "main" and steps >= 50:  # not in the few-step counter passes: their per-kernel averages are the step's launches
         tracks["klt_with_err_output"] = klt_full_call_ms(L)
     return elapsed, kernels, roofline_for(kernels, counters, leg, batch), tracks, note
 
