@@ -67,15 +67,6 @@ extern "C" int vfe_dev_compact_tracks(const float* pts, const uint8_t* status, c
     return VFE_OK;
 }
 
-/* the same with a second copy of the counts (the front-end step reports them as n_tracked: no copy launch behind it) */
-static int compact_tracks2(const float* pts, const uint8_t* status, const int* n_pts, int cap, int batch, int width, int height,
-                           int border, float* out_pts, int* out_n, int* out_n2, hipStream_t st) {
-    ProfScope prof(VFE_K_COMPACT, st);
-    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, pts, status, n_pts, cap, width, height, border, out_pts, out_n, out_n2);
-    VFE_LAUNCH_CHECK();
-    return VFE_OK;
-}
-
 extern "C" int vfe_dev_append_points(float* pts, int* n_pts, int cap, int batch,
                                      const float* extra, const int* n_extra, int extra_cap, void* stream) {
     VFE_REQUIRE(pts && n_pts && extra && n_extra, "NULL buffer");
@@ -332,12 +323,12 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
     if ((rc = klt_track_ordered(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
                                 win, max_iter, eps, min_eig_thr, 0, order, st))) return rc;
     if (reject && reject->f_threshold > 0 && (rc = fe_reject(reject, pts, next_pts, n_pts, cap, batch, w, h, status, st))) return rc;
-    if ((rc = compact_tracks2(next_pts, status, n_pts, cap, batch, w, h, 1, pts, n_pts, n_tracked, st))) return rc;
+    /* the selection gathers the surviving tracks itself (no compaction launch between the tracker and the selection) */
     if (aux) {
         VFE_HIP(hipStreamWaitEvent(st, aux->join, 0));
         guard.joined = true;
     } else if ((rc = gf_eig_phase(&next_levels[0], cap, quality, min_distance, cap, ws + L.gf_off, L.gf_bytes, st))) return rc;
     /* the selection appends what it accepts to the tracked points itself (one launch less at the serial end of the step) */
     return gf_select_phase(&next_levels[0], cap, quality, min_distance, pts, n_pts, cap, corners, nullptr, counts,
-                           ws + L.gf_off, L.gf_bytes, st, true);
+                           ws + L.gf_off, L.gf_bytes, st, true, next_pts, status, n_tracked);
 }

@@ -55,4 +55,7 @@ int gf_eig_phase(const vfe_dimg* img, int max_corners, double quality, double mi
 int gf_select_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance,
                     const float* seeds_xy, const int* n_seeds, int seed_cap,
                     float* corners_xy, float* scores, int* counts, void* workspace, size_t workspace_bytes, hipStream_t st,
-                    bool append);
+                    bool append, const float* cmp_src = nullptr, const uint8_t* cmp_status = nullptr, int* cmp_n_out = nullptr);
+/* cmp_src / cmp_status (append mode): the selection first gathers the frame's surviving tracks itself -- those of
+ * cmp_src[b][0 .. n_seeds[b]) with status set and a rounded position inside the image less a one-pixel rim, in order -- into
+ * seeds_xy, and reports their number in cmp_n_out (may be NULL): what vfe_dev_compact_tracks would do in a launch of its own */

@@ -53,6 +53,13 @@ struct SelParams {
      * with n the clamped seed count, and the count becomes n + accepted -- the seeds' own arrays, [batch][seed_cap] */
     float* append_pts;
     int* append_n;
+    /* compaction in front (append mode only, or cmp_src = NULL): the frame's tracked points are first gathered -- stably --
+     * from cmp_src[b][0 .. n_seeds[b]) where cmp_status is set and the rounded position lies inside the image less a
+     * one-pixel rim, into seeds[b][...]; the count goes to n_seeds[b] and cmp_n_out[b] (may be NULL).  One launch less
+     * between the tracker and the selection. */
+    const float* cmp_src;
+    const uint8_t* cmp_status;
+    int* cmp_n_out;
 };
 
 __device__ static inline u32 ld_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -128,7 +135,37 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
 
     if (tid == 0) { s_cnt = 0; s_nacc = 0; }
     /* refill budget: tracked points count towards max_corners */
-    const int ns = (p.seeds && p.n_seeds) ? max(0, min(p.n_seeds[b], p.seed_cap)) : 0;
+    int ns = (p.seeds && p.n_seeds) ? max(0, min(p.n_seeds[b], p.seed_cap)) : 0;
+    if (p.cmp_src) {
+        const int n_in = ns, lane = tid & 63, wv = tid >> 6;
+        const float* src = p.cmp_src + (size_t)b * p.seed_cap * 2;
+        const uint8_t* stt = p.cmp_status + (size_t)b * p.seed_cap;
+        float* dst = p.append_pts + (size_t)b * p.seed_cap * 2;
+        int base = 0;
+        for (int start = 0; start < n_in; start += SEL_THREADS) {
+            const int i = start + tid;
+            bool keep = false;
+            float x = 0.f, y = 0.f;
+            if (i < n_in && stt[i]) {
+                x = src[2 * i]; y = src[2 * i + 1];
+                const int ix = __float2int_rn(x), iy = __float2int_rn(y);
+                keep = ix >= 1 && ix < p.W - 1 && iy >= 1 && iy < p.H - 1;
+            }
+            const u64 m = __ballot(keep);
+            const int pre = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_scan[0][wv] = (u32)__popcll(m);
+            __syncthreads();
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int k = 0; k < SEL_THREADS / 64; k++) { const int c = (int)s_scan[0][k]; if (k < wv) off += c; tot += c; }
+            __syncthreads();
+            if (keep) { dst[2 * (base + off + pre)] = x; dst[2 * (base + off + pre) + 1] = y; }
+            base += tot;
+        }
+        ns = base;
+        if (tid == 0 && p.cmp_n_out) p.cmp_n_out[b] = ns;
+        __syncthreads(); /* the gathered points are read back below by other threads */
+    }
     const int limit = max(0, p.max_corners - ns);
     if (limit == 0) { /* nothing to add: the frame keeps its tracked points */
         if (tid == 0) { p.counts[b] = 0; if (p.append_n) p.append_n[b] = ns; }
@@ -520,7 +557,7 @@ int gf_eig_phase(const vfe_dimg* img, int max_corners, double quality, double mi
 int gf_select_phase(const vfe_dimg* img, int max_corners, double quality, double min_distance,
                     const float* seeds_xy, const int* n_seeds, int seed_cap,
                     float* corners_xy, float* scores, int* counts, void* workspace, size_t workspace_bytes, hipStream_t st,
-                    bool append) {
+                    bool append, const float* cmp_src, const uint8_t* cmp_status, int* cmp_n_out) {
     GfWs L;
     int rc = gf_check(img, max_corners, quality, min_distance, seeds_xy, n_seeds, &seed_cap, corners_xy, counts, workspace,
                       workspace_bytes, &L);
@@ -544,6 +581,8 @@ int gf_select_phase(const vfe_dimg* img, int max_corners, double quality, double
         VFE_REQUIRE(seeds_xy && n_seeds && seed_cap == max_corners, "append mode needs the seed arrays with max_corners slots per frame");
         p.append_pts = const_cast<float*>(seeds_xy); p.append_n = const_cast<int*>(n_seeds);
     }
+    VFE_REQUIRE(!cmp_src || (append && cmp_status && cmp_src != seeds_xy), "compaction in front needs append mode and its own source array");
+    p.cmp_src = cmp_src; p.cmp_status = cmp_status; p.cmp_n_out = cmp_n_out;
     {
         ProfScope prof(VFE_K_GFTT_SELECT, st);
         hipLaunchKernelGGL(k_gftt_select, dim3(img->batch), dim3(SEL_THREADS), 0, st, p);
@@ -562,7 +601,7 @@ extern "C" int vfe_dev_good_features(const vfe_dimg* img, int max_corners, doubl
     if (rc) return rc;
     if ((rc = gf_eig_phase(img, max_corners, quality, min_distance, sc, workspace, workspace_bytes, (hipStream_t)stream))) return rc;
     return gf_select_phase(img, max_corners, quality, min_distance, seeds_xy, n_seeds, sc, corners_xy, scores, counts, workspace,
-                           workspace_bytes, (hipStream_t)stream, false);
+                           workspace_bytes, (hipStream_t)stream, false, nullptr, nullptr, nullptr);
 }
 
 extern "C" int vfe_dev_min_eigen_map(const vfe_dimg* img, float* eig, void* stream) {
