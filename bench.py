@@ -440,9 +440,11 @@ def klt_full_call_ms(L, reps=10):
     out = [torch.zeros_like(pts), torch.zeros(pts.shape[:2], dtype=torch.uint8, device=pts.device),
            torch.zeros(pts.shape[:2], dtype=torch.float32, device=pts.device)]
     res = {}
-    for name, err in (("without_err_ms", False), ("with_err_ms", True)):
-        call = (lambda: capi.klt_track(prev, nxt, pts, n, out[0], out[1], out[2], win=WIN)) if err else \
-               (lambda: capi.klt_track_no_err(prev, nxt, pts, n, out[0], out[1], win=WIN))
+    ws = torch.empty(capi.lib().vfe_klt_track_workspace(pts.shape[1], pts.shape[0]), dtype=torch.uint8, device=pts.device)
+    calls = {"without_err_ms": lambda: capi.klt_track_no_err(prev, nxt, pts, n, out[0], out[1], win=WIN),
+             "with_err_ms": lambda: capi.klt_track(prev, nxt, pts, n, out[0], out[1], out[2], win=WIN),
+             "with_err_own_order_ms": lambda: capi.klt_track_ws(prev, nxt, pts, n, out[0], out[1], out[2], win=WIN, workspace=ws)}
+    for name, call in calls.items():
         call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -451,8 +453,9 @@ def klt_full_call_ms(L, reps=10):
         e1.record()
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / reps
-    res["what"] = ("vfe_dev_klt_track on the leg's pyramids and points in caller order (no tile / rim ordering), with and "
-                   "without the err output of calcOpticalFlowPyrLK; the front-end step runs the form without")
+    res["what"] = ("vfe_dev_klt_track on the leg's pyramids and points in caller order, with and without the err output of "
+                   "calcOpticalFlowPyrLK (the front-end step runs the form without), and vfe_dev_klt_track_ws, which orders "
+                   "the points itself (order kernel included in the time)")
     return res
 
 

@@ -639,3 +639,43 @@ def test_frontend_step_fast_grid_bit_exact(cuda):
         keep1 = int(got_n[1]) * 2 // 3
         fe.n_pts[1] = keep1
         ref[1] = ref[1][:keep1]
+
+
+@pytest.mark.parametrize("w,h,levels,npts,win", [(752, 480, 3, 150, 21), (1920, 1080, 4, 600, 21), (640, 480, 3, 100, 15)])
+def test_klt_track_with_workspace_gives_the_same_results(cuda, w, h, levels, npts, win):
+    """vfe_dev_klt_track_ws tracks a frame's points in its own order (rim class, then tile); every result lands at its
+    point's index, bit for bit what vfe_dev_klt_track and the oracle give -- points on and beyond the rim, ragged
+    counts, the err output, and a window size for which the workspace is ignored."""
+    import torch
+    seqs = [synth.BASE_SEED + 40 + s for s in range(3)]
+    prev = [synth.scene(s, w, h, 0) for s in seqs]
+    nxt = [synth.scene(s, w, h, 1) for s in seqs]
+    rng = np.random.default_rng(7)
+    P = np.zeros((3, npts, 2), np.float32)
+    n = np.array([npts, npts - 37, 5], np.int32)
+    for i, im in enumerate(prev):
+        xy, _ = ora.good_features(im, npts, 0.01, 8)
+        xy = xy + np.float32(0.25) * (np.arange(len(xy))[:, None] % 4).astype(np.float32)
+        k = min(len(xy), npts)
+        P[i, :k] = xy[:k]
+        P[i, k:] = rng.uniform([0, 0], [w - 1, h - 1], (npts - k, 2))
+        P[i, :6] = [[1.5, 2.25], [w - 2.0, h - 1.5], [-5.0, 10.0], [9.75, h / 2], [w / 2, 10.5], [w - 11.0, h - 11.0]]
+    pl = capi.build_pyramid(capi.alloc_pyramid(to_dev(prev, cuda), levels))
+    nl = capi.build_pyramid(capi.alloc_pyramid(to_dev(nxt, cuda), levels))
+    dP, dn = torch.from_numpy(P).to(cuda), torch.from_numpy(n).to(cuda)
+    a_out, a_st, a_err = capi.klt_track(pl, nl, dP, dn, win=win)
+    b_out = torch.full_like(dP, -7.0)
+    b_st = torch.zeros((3, npts), dtype=torch.uint8, device=cuda)
+    b_err = torch.zeros((3, npts), dtype=torch.float32, device=cuda)
+    capi.klt_track_ws(pl, nl, dP, dn, b_out, b_st, b_err, win=win)
+    for i in range(3):
+        k = int(n[i])
+        assert torch.equal(a_st[i, :k], b_st[i, :k])
+        assert torch.equal(a_out[i, :k].view(torch.int32), b_out[i, :k].view(torch.int32))
+        assert torch.equal(a_err[i, :k].view(torch.int32), b_err[i, :k].view(torch.int32))
+        ro, rs, re = ora.klt_track(prev[i], nxt[i], P[i, :k], win, levels - 1)
+        assert np.array_equal(b_st[i, :k].cpu().numpy(), rs)
+        assert np.array_equal(b_out[i, :k].cpu().numpy().view(np.uint32), ro.view(np.uint32))
+    # too small a workspace is an error, not a silent fallback
+    with pytest.raises(capi.VfeError):
+        capi.klt_track_ws(pl, nl, dP, dn, b_out, b_st, b_err, win=21, workspace=torch.empty(256, dtype=torch.uint8, device=cuda))

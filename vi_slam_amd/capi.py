@@ -71,6 +71,9 @@ SIGNATURES = {
     "vfe_dev_min_eigen_map": (C.c_int, [_DI, _P, _P]),
     "vfe_dev_klt_track": (C.c_int, [_DI, _DI, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_double,
                                     C.c_double, C.c_int, _P]),
+    "vfe_klt_track_workspace": (C.c_size_t, [C.c_int, C.c_int]),
+    "vfe_dev_klt_track_ws": (C.c_int, [_DI, _DI, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_double,
+                                       C.c_double, C.c_int, _P, C.c_size_t, _P]),
     "vfe_dev_klt_track_bidir": (C.c_int, [_DI, _DI, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                           C.c_double, C.c_double, C.c_double, _P]),
     "vfe_dev_undistort_points": (C.c_int, [_P, _P, C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
@@ -266,6 +269,22 @@ def klt_track(prev_levels, next_levels, prev_pts, n_pts=None, next_pts=None, sta
     na = (DImg * n)(*[dimg(t) for t in next_levels])
     check(lib().vfe_dev_klt_track(pa, na, n, _ptr(prev_pts), _ptr(n_pts), cap, _ptr(next_pts), _ptr(status),
                                   _ptr(err), win, max_iter, eps, min_eig_thr, 1 if use_initial_flow else 0, _stream()))
+    return next_pts, status, err
+
+
+def klt_track_ws(prev_levels, next_levels, prev_pts, n_pts, next_pts, status, err=None, win=21, max_iter=30, eps=0.01,
+                 min_eig_thr=1e-4, use_initial_flow=False, workspace=None):
+    """vfe_dev_klt_track_ws: the tracker with a workspace for its own processing order (same results)."""
+    import torch
+    b, cap, _ = prev_pts.shape
+    if workspace is None:
+        workspace = torch.empty(lib().vfe_klt_track_workspace(cap, b), dtype=torch.uint8, device=prev_pts.device)
+    n = len(prev_levels)
+    pa = (DImg * n)(*[dimg(t) for t in prev_levels])
+    na = (DImg * n)(*[dimg(t) for t in next_levels])
+    check(lib().vfe_dev_klt_track_ws(pa, na, n, _ptr(prev_pts), _ptr(n_pts), cap, _ptr(next_pts), _ptr(status), _ptr(err),
+                                     win, max_iter, eps, min_eig_thr, 1 if use_initial_flow else 0,
+                                     _ptr(workspace), workspace.numel(), _stream()))
     return next_pts, status, err
 
 

@@ -253,6 +253,32 @@ extern "C" int vfe_dev_klt_track(const vfe_dimg* prev_levels, const vfe_dimg* ne
                              min_eig_thr, use_initial_flow, nullptr, (hipStream_t)stream);
 }
 
+extern "C" size_t vfe_klt_track_workspace(int pts_cap, int batch) {
+    if (pts_cap <= 0 || batch <= 0) return 0;
+    return align_up((size_t)pts_cap * (size_t)batch * sizeof(unsigned short), 256);
+}
+
+extern "C" int vfe_dev_klt_track_ws(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                                    const float* prev_pts, const int* n_pts, int pts_cap,
+                                    float* next_pts, uint8_t* status, float* err,
+                                    int win, int max_iter, double eps, double min_eig_thr, int use_initial_flow,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    VFE_REQUIRE(prev_levels && next_levels && nlevels >= 1 && nlevels <= KLT_MAX_LEVELS, "nlevels must be 1..8");
+    VFE_REQUIRE(prev_pts && pts_cap > 0, "NULL point buffers");
+    const unsigned short* order = nullptr;
+    if (win == 21 && pts_cap <= 65536 && workspace) {
+        VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+        const int batch = prev_levels[0].batch;
+        VFE_REQUIRE(batch > 0 && workspace_bytes >= vfe_klt_track_workspace(pts_cap, batch), "workspace too small");
+        int rc = klt_order_launch(prev_pts, n_pts, pts_cap, batch, prev_levels[0].width, prev_levels[0].height, nlevels,
+                                  (unsigned short*)workspace, (hipStream_t)stream);
+        if (rc) return rc;
+        order = (const unsigned short*)workspace;
+    }
+    return klt_track_ordered(prev_levels, next_levels, nlevels, prev_pts, n_pts, pts_cap, next_pts, status, err, win, max_iter, eps,
+                             min_eig_thr, use_initial_flow, order, (hipStream_t)stream);
+}
+
 int klt_track_ordered(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
                       const float* prev_pts, const int* n_pts, int pts_cap, float* next_pts, uint8_t* status, float* err,
                       int win, int max_iter, double eps, double min_eig_thr, int use_initial_flow,
