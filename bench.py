@@ -509,42 +509,13 @@ def run_orb_match_leg(rk, frames, batch, steps, warmup, counters):
             "roofline": roofline_for(kernels, counters, "orb_match", batch), "kernels": kernels}
 
 
-def planted_position(i):
-    return (i * 4999 + 1234567) % MAP_ROWS  # 4999 is coprime to 10^7: distinct rows
-
-
-def verify_planted(q, idx, dist_):
-    """Known answers of the relocalisation leg.  Query i has a planted row (i % 21 flipped bits) at planted_position(i);
-    ORB queries can be near-duplicates of each other, so the expected neighbours of query i are the best two of ALL
-    planted rows by (distance, global row), computed here on the host from the 2000 x 2000 distances.  Unplanted rows are
-    uniform random bits (about 128 +- 8 bits away from anything; the closest of 10 M is ~85 bits away), so they cannot enter a
-    top-2 whose distances are below 60.  -> (all as expected, number of queries whose top-1 is their own planted row)."""
-    from vi_slam_amd import synth
-    n = len(q)
-    planted = np.stack([synth.flip_bits(i, q[i], i % 21) for i in range(n)])
-    pos = np.array([planted_position(i) for i in range(n)], np.int64)
-    q64, p64 = q.view(np.uint64), planted.view(np.uint64)
-    ok, own = True, 0
-    for i0 in range(0, n, 250):
-        d = np.bitwise_count(q64[i0:i0 + 250, None, :] ^ p64[None, :, :]).sum(axis=2).astype(np.int64)  # [250, n]
-        key = d * (1 << 32) + pos[None, :]
-        best = np.argsort(key, axis=1)[:, :2]
-        for r in range(d.shape[0]):
-            i = i0 + r
-            j0, j1 = best[r]
-            ok &= bool(idx[i, 0] == pos[j0] and dist_[i, 0] == d[r, j0])
-            if d[r, j1] < 60:
-                ok &= bool(idx[i, 1] == pos[j1] and dist_[i, 1] == d[r, j1])
-            own += int(idx[i, 0] == pos[i])
-    return ok, own
-
-
-def run_reloc_leg(rk, steps, warmup, counters):
+def run_reloc_leg(rk, steps, warmup, counters, force_collective=False):
     """configs[4]: 2000 queries against a 10 M-row map, rows [shard_range(10 M, rank, world)) on this rank; per-shard
     top-2 all-gathered and merged by (distance, global index).  Every query has a planted near-duplicate
     (<= 20 flipped bits) at a known global row: top-1 must be exactly that row at exactly that distance."""
     import torch
     from vi_slam_amd import capi, dist as vdist, synth
+    from vi_slam_amd.planted import map_shard, verify_planted
     b, e = vdist.shard_range(MAP_ROWS, rk.rank, rk.world)
     # queries: ORB descriptors of the first frame of the base scene (the same on every rank), padded to 2000 if short
     img = capi.alloc_image(1, H, W, rk.dev)
@@ -555,17 +526,13 @@ def run_reloc_leg(rk, steps, warmup, counters):
     q = np.concatenate([desc[:N_QUERIES], synth.descriptors(synth.MAP_SEED + 1, max(0, N_QUERIES - len(desc)))])[:N_QUERIES]
     q = np.ascontiguousarray(q)
     del orb, img
-    shard = synth.descriptors(synth.MAP_SEED, e - b, first=b)
-    for i in range(N_QUERIES):
-        p = planted_position(i)
-        if b <= p < e:
-            shard[p - b] = synth.flip_bits(i, q[i], i % 21)
+    shard = map_shard(q, b, e)
     qd, td = torch.from_numpy(q).to(rk.dev), torch.from_numpy(shard).to(rk.dev)
     del shard
     res = {}
 
     def step():
-        res["r"] = vdist.sharded_match_knn2(qd, td, b)
+        res["r"] = vdist.sharded_match_knn2(qd, td, b, force_collective=force_collective)
 
     elapsed, prof = timed(rk, step, steps, warmup)
     idx, dist_ = res["r"]
@@ -581,7 +548,8 @@ def run_reloc_leg(rk, steps, warmup, counters):
                        f"{rk.world} GPU(s), per-shard top-2 all-gathered (32 000 B per rank) and merged",
            "value": N_QUERIES * steps / elapsed, "unit": "queries/s", "ms_per_query_set": elapsed / steps * 1e3, "steps": steps,
            "pairs_per_s": pairs / elapsed, "rows_per_gpu": rows, "planted_neighbours_verified": ok, "queries_whose_top1_is_their_own_planted_row": exact_top1,
-           "collective": "all_gather (RCCL)" if rk.world > 1 and not rk.gloo else ("all_gather (gloo rehearsal)" if rk.world > 1 else "none (one shard)"),
+           "collective": ("all_gather (RCCL)" if rk.world > 1 and not rk.gloo else "all_gather (gloo rehearsal)" if rk.world > 1
+                          else "all_gather (RCCL, one-rank group, forced)" if force_collective else "none (one shard)"),
            "roofline": roof, "kernels": kernels}
     if "k_match" in kernels:
         # the search kernel alone (sample + main launch of a step), without all-gather and merges
@@ -633,6 +601,9 @@ def main():
                     help="comma-separated legs to run (main always runs)")
     ap.add_argument("--orb-batch", type=int, default=64, help="streams per GPU in the orb_match leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: initialise a one-rank RCCL group and run the reloc leg's all-gather + merge through it, "
+                         "so that the exchange executes on a one-GPU machine (same results, the collective's cost included)")
     ap.add_argument("--rehearse-one-device", action="store_true",
                     help="multi-rank rehearsal on a box with one GPU: every rank uses cuda:0 and the collectives go over gloo "
                          "(RCCL refuses two ranks on one device); not a measurement")
@@ -642,6 +613,11 @@ def main():
         sys.exit(launch_ranks(args.gpus) if not args.rehearse_one_device else launch_rehearsal(args.gpus))
     overlap = args.overlap == "on"
     legs = set(args.legs.split(","))
+    # stdout carries the one JSON line and nothing else: libraries that print to descriptor 1 (RCCL writes a version banner
+    # there when a group is initialised) are sent to stderr, the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -665,6 +641,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif args.force_collective:  # a one-rank RCCL group, set up before any other GPU work of this process
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     capi.lib()
     if os.environ.get("VFE_BENCH_WATCHDOG"):  # stack traces of every thread if a leg stalls (debugging aid)
         import faulthandler
@@ -736,7 +717,7 @@ def main():
     torch.cuda.empty_cache()
     if "reloc" in legs:
         log("reloc leg")
-        out["reloc"] = run_reloc_leg(rk, max(10, args.steps // 10), 3, counters)
+        out["reloc"] = run_reloc_leg(rk, max(10, args.steps // 10), 3, counters, args.force_collective)
     rk.barrier()
     if rank == 0:
         log("single_stream / cpu_baseline legs")
@@ -746,9 +727,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host, args.loss, n_distinct)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["one_core"]["value"]
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     rk.barrier()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

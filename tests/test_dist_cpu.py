@@ -74,3 +74,41 @@ def test_sharded_match_over_gloo_equals_single_scan(world):
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _forced_worker(port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    q = synth.descriptors(3, 50)
+    t = synth.descriptors(4, 900)
+    merges = []
+
+    def merge(ai, ad):
+        merges.append(tuple(ai.shape))
+        return _numpy_merge(ai, ad)
+    try:
+        vdist.sharded_match_knn2(torch.from_numpy(q), torch.from_numpy(t), 11, match_fn=_oracle_match, merge_fn=merge,
+                                 force_collective=True)
+        ret["raised"] = False
+    except RuntimeError:
+        ret["raised"] = True   # no process group: the forced exchange cannot run and says so
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    plain = vdist.sharded_match_knn2(torch.from_numpy(q), torch.from_numpy(t), 11, match_fn=_oracle_match, merge_fn=merge)
+    assert merges == []         # one rank, not forced: the scan's result is returned as it is
+    idx, d = vdist.sharded_match_knn2(torch.from_numpy(q), torch.from_numpy(t), 11, match_fn=_oracle_match, merge_fn=merge,
+                                      force_collective=True)
+    ret["merges"] = list(merges)
+    ret["equal"] = bool(torch.equal(idx, plain[0]) and torch.equal(d, plain[1]))
+    dist.destroy_process_group()
+
+
+def test_forced_collective_in_a_one_rank_group():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_forced_worker, args=(port, ret))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    assert ret["raised"] is True and ret["equal"] is True
+    assert ret["merges"] == [(1, 50, 2)]

@@ -124,6 +124,36 @@ def test_relocalisation_shard_properties(cuda):
     assert np.array_equal(hi[sel], ridx) and np.array_equal(hd[sel], rdist)
 
 
+def test_relocalisation_full_map_2000_x_10M(cuda):
+    """configs[4] at its full size on one GPU: 2000 queries against the 10 M-row map with a planted near-duplicate per
+    query at a known row.  Every top-1 (and every top-2 below 60 bits) must be the expected planted row at the expected
+    distance; scanning the map as 8 shards of shard_range(10 M, r, 8) and merging the lists must give the same answer;
+    the allocation-free entry point (sample lists and floors in the built-in scratch) must agree bit for bit."""
+    import torch
+    from vi_slam_amd import dist as vdist
+    from vi_slam_amd.planted import MAP_ROWS, N_QUERIES, map_shard, planted_position, verify_planted
+    q = synth.descriptors(21, N_QUERIES)
+    q[7] = q[3]                      # two identical queries: each sees both planted rows, lower row first on a tie
+    t = map_shard(q, 0, MAP_ROWS)
+    qd, td = torch.from_numpy(q).to(cuda), torch.from_numpy(t).to(cuda)
+    del t
+    idx, dist = capi.match_knn2(qd, td)
+    hi, hd = idx.cpu().numpy(), dist.cpu().numpy()
+    ok, own = verify_planted(q, hi, hd)
+    assert ok
+    assert own >= N_QUERIES - 2      # all but the duplicated pair (whichever of the two rows is closer / lower wins)
+    assert len({planted_position(i) for i in range(N_QUERIES)}) == N_QUERIES
+    si, sd = [], []
+    for r in range(8):
+        b, e = vdist.shard_range(MAP_ROWS, r, 8)
+        i_, d_ = capi.match_knn2(qd, td[b:e], base_index=b)
+        si.append(i_); sd.append(d_)
+    midx, mdist = capi.merge_knn2(torch.stack(si), torch.stack(sd))
+    assert torch.equal(midx, idx) and torch.equal(mdist, dist)
+    nidx, ndist = capi.match_knn2_noalloc(qd, td)
+    assert torch.equal(nidx, idx) and torch.equal(ndist, dist)
+
+
 def test_frontend_64_streams_1080p(cuda):
     """configs[3] at its stated shape: 64 independent 1080p streams (8 distinct sequences, each eight times) through
     vfe_dev_frontend_step for three steps; every stream's point set equals the oracle's sequence bit for bit, and copies

@@ -21,11 +21,13 @@ def streams_for_rank(n_streams, rank, world):
     return list(range(b, e))
 
 
-def sharded_match_knn2(query, train_shard, base_index, group=None, match_fn=None, merge_fn=None):
+def sharded_match_knn2(query, train_shard, base_index, group=None, match_fn=None, merge_fn=None, force_collective=False):
     """Global kNN-2 of `query` against a map whose rows [base_index, base_index + len(train_shard))
     live on this rank.  query / train_shard: uint8 tensors [n, 32] on this rank's device.
     Returns (idx [nq, 2], dist [nq, 2]) identical on every rank.
-    match_fn / merge_fn default to the HIP entry points (vfe_dev_match_knn2 / vfe_dev_merge_knn2)."""
+    match_fn / merge_fn default to the HIP entry points (vfe_dev_match_knn2 / vfe_dev_merge_knn2).
+    force_collective: run the all-gather and the merge in a one-rank group too (needs an initialised process group);
+    a one-GPU machine exercises the exchange that way, the result is that of the plain scan."""
     import torch
     import torch.distributed as dist
     if match_fn is None or merge_fn is None:
@@ -34,7 +36,9 @@ def sharded_match_knn2(query, train_shard, base_index, group=None, match_fn=None
         merge_fn = merge_fn or capi.merge_knn2
     idx, d = match_fn(query, train_shard, base_index)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if force_collective and not dist.is_initialized():
+        raise RuntimeError("force_collective needs an initialised torch.distributed process group")
+    if world == 1 and not force_collective:
         return idx, d
     packed = torch.stack([idx, d]).contiguous()           # [2, nq, 2] int32: one message per rank
     device = packed.device
