@@ -46,8 +46,13 @@ $(LIBDIR)/libvfe.so: $(HIP_OBJS) | $(LIBDIR)
 $(LIBDIR)/libvi_slam_amd.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/libvfe.so
 	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -I$(HOST)/include -Iinclude -shared -o $@ $(HOST_SRCS) -L$(LIBDIR) -lvfe -Wl,-rpath,'$$ORIGIN' -lpthread
 
+# the soak program also asks the HIP runtime how much device memory is in use
+tests/cpp/bin/test_soak: tests/cpp/test_soak.cpp tests/cpp/gpu_test_frames.hpp $(LIBDIR)/libvi_slam_amd.so
+	@mkdir -p tests/cpp/bin
+	$(CXX) -O1 -std=c++17 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$(HOST)/include -Iinclude -o $@ $< -L$(LIBDIR) -lvi_slam_amd -lvfe -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib -lpthread
+
 # lifecycle tests in the reference's style (plain main(), exit code 1 on failure)
-tests/cpp/bin/%: tests/cpp/%.cpp $(LIBDIR)/libvi_slam_amd.so
+tests/cpp/bin/%: tests/cpp/%.cpp tests/cpp/gpu_test_frames.hpp $(LIBDIR)/libvi_slam_amd.so
 	@mkdir -p tests/cpp/bin
 	$(CXX) -O1 -std=c++17 -Wall -I$(HOST)/include -Iinclude -o $@ $< -L$(LIBDIR) -lvi_slam_amd -lvfe -Wl,-rpath,'$$ORIGIN/../../../$(LIBDIR)' -lpthread
 

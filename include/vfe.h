@@ -241,7 +241,10 @@ int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg* next_leve
 /* vfe_dev_frontend_step runs the detector's eigenvalue pass on a helper stream of the library (one per host thread and
  * device, forked from and joined back into the caller's stream) beside pyramid + tracker: mode 1 (default).  mode 0
  * keeps every kernel on the caller's stream, in order -- what a profiler wants to see.  The environment variable
- * VFE_OVERLAP=0/1 sets the initial mode.  Process-wide.  No counterpart in the reference, whose adapters make one
+ * VFE_OVERLAP=0/1 sets the initial mode.  Process-wide (a context overrides it for its own calls with vfe_ctx_set_overlap).
+ * The helper stream and its events are created by the first overlapped call of a host thread on a device; a call whose
+ * stream is being captured into a graph before that has happened runs on the caller's stream alone, so warm up with one
+ * un-captured step if the captured graph should contain the fork.  No counterpart in the reference, whose adapters make one
  * blocking OpenCV call per frame (src/slam/adapters/openvins_adapter.cpp:78-80). */
 int vfe_set_overlap(int mode);
 
@@ -295,6 +298,8 @@ int vfe_prof_enable(int enable);
  * clears the totals afterwards. */
 int vfe_prof_read(double* ms, long long* launches, int reset);
 const char* vfe_prof_kernel_name(int id);
+/* vfe_set_overlap and vfe_prof_enable / vfe_prof_read are process-wide: they govern the vfe_dev_* entry points and every
+ * context that has not made a choice of its own with vfe_ctx_set_overlap / vfe_ctx_prof_enable (below). */
 
 /* ---- FAST ------------------------------------------------------------------------------ */
 
@@ -405,6 +410,14 @@ int vfe_create(const vfe_config* cfg, vfe_ctx** out);
 void vfe_destroy(vfe_ctx* ctx);
 /* forget the previous frame and all tracks (ISLAMFramework::reset, i_slam_framework.hpp:103) */
 int vfe_reset(vfe_ctx* ctx);
+/* Per-context forms of vfe_set_overlap and vfe_prof_enable / vfe_prof_read, so that two engines in one process do not
+ * switch each other's settings (an engine is one context: reference src/slam/slam_engine.cpp:94-119 serialises one
+ * framework under one mutex).  mode 0 / 1: this context's calls run with the setting off / on whatever the process-wide
+ * switch says; -1 (the state after vfe_create): follow the process-wide switch.  Launches timed for a context are
+ * summed apart from everybody else's and read with vfe_ctx_prof_read (same arrays as vfe_prof_read). */
+int vfe_ctx_set_overlap(vfe_ctx* ctx, int mode);
+int vfe_ctx_prof_enable(vfe_ctx* ctx, int mode);
+int vfe_ctx_prof_read(vfe_ctx* ctx, double* ms, long long* launches, int reset);
 /* Every frame handed to the calls below is equalised on the GPU after upload / BGR conversion and before
  * anything else reads it.  mode VFE_EQ_HIST: cv::equalizeHist (`equalize: 1` of reference
  * config/vins_mono.yaml:104); VFE_EQ_CLAHE: CLAHE with clip 10.0 on 8 x 8 tiles (`histogram_method: "CLAHE"`,

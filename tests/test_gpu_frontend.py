@@ -485,6 +485,55 @@ def test_frontend_step_under_graph_capture(cuda):
     assert int(want_n.min()) > n // 2
 
 
+def test_first_frontend_step_of_a_thread_under_graph_capture(cuda):
+    """The helper stream for the detector is made by a host thread's first overlapped step; when that first step happens
+    while the caller's stream is being captured, nothing may be created: the captured step runs on the caller's stream
+    alone and replays to the same points as a directly enqueued one."""
+    import threading
+    import torch
+    w, h, n, d, levels, q, B = 480, 320, 150, 10, 3, 0.01, 2
+    seq = [[synth.scene(synth.BASE_SEED + 90 + b, w, h, t) for t in range(2)] for b in range(B)]
+    frames = [to_dev([seq[b][t] for b in range(B)], cuda) for t in range(2)]
+
+    def fresh():
+        fe = capi.FrontendStep(B, h, w, n, levels, 21, quality=q, min_distance=d, device=cuda)
+        pyr = [capi.alloc_pyramid(frames[0], levels), capi.alloc_pyramid(frames[1], levels)]
+        capi.build_pyramid(pyr[0])
+        gf = capi.GoodFeatures(B, h, w, n, device=cuda)
+        c, _, cnt = gf(frames[0], q, d)
+        fe.pts.copy_(c); fe.n_pts.copy_(cnt)
+        return fe, pyr
+
+    fe, pyr = fresh()
+    fe.step(pyr[0], pyr[1])
+    torch.cuda.synchronize()
+    want_pts, want_n = fe.pts.clone(), fe.n_pts.clone()
+    result = {}
+
+    def in_new_thread():  # a thread that has never stepped: it owns no helper stream yet
+        try:
+            torch.cuda.set_device(cuda)
+            fe2, pyr2 = fresh()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                g.capture_begin(capture_error_mode="thread_local")
+                fe2.step(pyr2[0], pyr2[1])
+                g.capture_end()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            result["ok"] = bool(torch.equal(fe2.n_pts, want_n) and torch.equal(fe2.pts, want_pts))
+        except Exception as e:  # noqa: BLE001 - reported to the asserting thread
+            result["error"] = repr(e)
+
+    th = threading.Thread(target=in_new_thread)
+    th.start(); th.join(120)
+    assert result.get("ok") is True, result
+    assert int(want_n.min()) > n // 2
+
+
 def test_frontend_step_many_streams_tile_order(cuda):
     """Enough points in the batch (streams x capacity >= 16384) for the tracker to take each frame's points tile by tile:
     48 streams that repeat three sequences, capacity 350; every stream equals the oracle's sequence and its repeats."""

@@ -12,7 +12,7 @@ from vi_slam_amd import engine as eng
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("prog", ["test_adapters_lifecycle", "test_slam_engine", "test_ingest"])
+@pytest.mark.parametrize("prog", ["test_adapters_lifecycle", "test_slam_engine", "test_ingest", "test_reference_shaped_adapter"])
 def test_cpp_lifecycle_programs(prog):
     exe = os.path.join(ROOT, "tests", "cpp", "bin", prog)
     assert os.path.exists(exe), "run `make` first"

@@ -117,6 +117,9 @@ SIGNATURES = {
     "vfe_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "vfe_destroy": (None, [_P]),
     "vfe_reset": (C.c_int, [_P]),
+    "vfe_ctx_set_overlap": (C.c_int, [_P, C.c_int]),
+    "vfe_ctx_prof_enable": (C.c_int, [_P, C.c_int]),
+    "vfe_ctx_prof_read": (C.c_int, [_P, _P, _P, C.c_int]),
     "vfe_set_equalize": (C.c_int, [_P, C.c_int]),
     "vfe_equalize_workspace": (C.c_size_t, [C.c_int]),
     "vfe_dev_equalize_hist": (C.c_int, [_DI, _DI, _P, C.c_size_t, _P]),

@@ -1,5 +1,6 @@
 /* Status / error plumbing of libvfe. */
 #include "vfe_common.h"
+#include <map>
 #include <stdarg.h>
 #include <string.h>
 #include <mutex>
@@ -45,16 +46,17 @@ extern "C" int vfe_device_count(int* count) {
 
 /* ---- kernel timing --------------------------------------------------------------------- */
 std::atomic<int> g_vfe_prof_on{0};
+thread_local const VfeCallOpts* t_vfe_call = nullptr;
 namespace {
-struct ProfRec { int id, dev; hipEvent_t a, b; };
+struct ProfRec { int id, dev; hipEvent_t a, b; const void* owner; }; /* owner: the context that asked for its own timing, or null */
 std::mutex g_prof_mu;                        /* guards the finished list, the event pool and the totals */
 /* begin recorded, end pending: scopes nest and close in order within a host thread, so the open list is per thread and
  * threads (or devices driven by different threads) cannot close each other's records */
 thread_local std::vector<ProfRec> g_prof_open;
 std::vector<ProfRec> g_prof_done;
 std::vector<std::vector<hipEvent_t>> g_prof_pool; /* spare events per device: an event belongs to the device it was created on */
-double g_prof_ms[VFE_K_COUNT];
-long long g_prof_n[VFE_K_COUNT];
+struct ProfTotals { double ms[VFE_K_COUNT]; long long n[VFE_K_COUNT]; };
+std::map<const void*, ProfTotals> g_prof_totals; /* key null: the process-wide totals */
 const size_t PROF_MAX_PENDING = 1u << 16;    /* nobody reading: stop recording rather than grow without bound */
 hipEvent_t prof_event(int dev) {
     if ((size_t)dev < g_prof_pool.size() && !g_prof_pool[dev].empty()) {
@@ -73,6 +75,7 @@ void prof_recycle(int dev, hipEvent_t e) {
 
 bool vfe_prof_begin(int id, hipStream_t st) {
     ProfRec r; r.id = id; r.dev = 0;
+    r.owner = (t_vfe_call && t_vfe_call->prof > 0) ? t_vfe_call->owner : nullptr;
     if (hipGetDevice(&r.dev) != hipSuccess) return false;
     {
         std::lock_guard<std::mutex> g(g_prof_mu);
@@ -102,24 +105,37 @@ void vfe_prof_end(int id, hipStream_t st) {
 
 extern "C" int vfe_prof_enable(int enable) { g_vfe_prof_on.store(enable ? 1 : 0); return VFE_OK; }
 
-extern "C" int vfe_prof_read(double* ms, long long* launches, int reset) {
+/* finished records of `owner` into its totals (the events' device must be current for nothing here: elapsed-time queries
+ * work from any device), then the totals out */
+int vfe_prof_read_owner(const void* owner, double* ms, long long* launches, int reset) {
     std::lock_guard<std::mutex> g(g_prof_mu);
+    ProfTotals& tot = g_prof_totals[owner];
+    size_t kept = 0;
     for (auto& r : g_prof_done) {
+        if (r.owner != owner) { g_prof_done[kept++] = r; continue; }
         float t = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess &&
             r.id >= 0 && r.id < VFE_K_COUNT) {
-            g_prof_ms[r.id] += t; g_prof_n[r.id] += 1;
+            tot.ms[r.id] += t; tot.n[r.id] += 1;
         }
         prof_recycle(r.dev, r.a); prof_recycle(r.dev, r.b);
     }
-    g_prof_done.clear();
+    g_prof_done.resize(kept);
     for (int i = 0; i < VFE_K_COUNT; i++) {
-        if (ms) ms[i] = g_prof_ms[i];
-        if (launches) launches[i] = g_prof_n[i];
-        if (reset) { g_prof_ms[i] = 0; g_prof_n[i] = 0; }
+        if (ms) ms[i] = tot.ms[i];
+        if (launches) launches[i] = tot.n[i];
+        if (reset) { tot.ms[i] = 0; tot.n[i] = 0; }
     }
     return VFE_OK;
 }
+
+void vfe_prof_forget_owner(const void* owner) {
+    (void)vfe_prof_read_owner(owner, nullptr, nullptr, 1);
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    g_prof_totals.erase(owner);
+}
+
+extern "C" int vfe_prof_read(double* ms, long long* launches, int reset) { return vfe_prof_read_owner(nullptr, ms, launches, reset); }
 
 extern "C" const char* vfe_prof_kernel_name(int id) {
     static const char* names[VFE_K_COUNT] = {"k_pyr_down", "k_gftt_eig", "k_gftt_select", "k_klt", "k_compact",

@@ -40,12 +40,26 @@ void vfe_set_error(const char* fmt, ...);
  * a pair of HIP events on the launch stream */
 #include <atomic>
 extern std::atomic<int> g_vfe_prof_on;
+/* Settings of the context whose entry point the calling thread is inside (null outside one): a context's own overlap /
+ * timing choice then wins over the process-wide switches, and its timing records are kept apart under `owner`.
+ * overlap / prof: -1 = follow the process-wide switch, 0 = off, 1 = on. */
+struct VfeCallOpts { const void* owner; int overlap, prof; };
+extern thread_local const VfeCallOpts* t_vfe_call;
+struct VfeCallScope {
+    const VfeCallOpts* saved;
+    explicit VfeCallScope(const VfeCallOpts* o) : saved(t_vfe_call) { t_vfe_call = o; }
+    ~VfeCallScope() { t_vfe_call = saved; }
+};
 bool vfe_prof_begin(int id, hipStream_t st); /* true when a record was opened (the matching end must then be called) */
 void vfe_prof_end(int id, hipStream_t st);
+int vfe_prof_read_owner(const void* owner, double* ms, long long* launches, int reset);
+void vfe_prof_forget_owner(const void* owner);
 struct ProfScope {
     int id; hipStream_t st; bool on;
     ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on(false) {
-        if (g_vfe_prof_on.load(std::memory_order_relaxed) != 0) on = vfe_prof_begin(id, st);
+        const VfeCallOpts* o = t_vfe_call;
+        const bool want = (o && o->prof >= 0) ? o->prof != 0 : g_vfe_prof_on.load(std::memory_order_relaxed) != 0;
+        if (want) on = vfe_prof_begin(id, st);
     }
     ~ProfScope() { if (on) vfe_prof_end(id, st); }
 };
@@ -55,7 +69,7 @@ struct ProfScope {
  * error returns included -- must leave the caller's stream waiting for the helper: the caller may free or reuse its
  * buffers as soon as it has the status code.  ForkGuard does that on scope exit unless the join has been made. */
 struct AuxStream { hipStream_t s; hipEvent_t fork, join; };
-AuxStream* vfe_aux_stream();
+AuxStream* vfe_aux_stream(hipStream_t caller);
 bool vfe_overlap_on();
 struct ForkGuard {
     AuxStream* a; hipStream_t st; bool joined;

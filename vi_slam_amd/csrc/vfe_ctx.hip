@@ -35,8 +35,10 @@ struct vfe_ctx {
      * copy from pageable memory is done row by row by the runtime, ~4 ms per MB); results come back
      * through h_io / h_small */
     uint8_t* h_stage[2]; size_t stage_bytes;
+    hipEvent_t stage_ev[2];             /* recorded behind the last copy out of each staging buffer */
     char* h_io; size_t io_bytes;
     int* h_small;
+    VfeCallOpts opts;                   /* this context's overlap / timing choice, seen by the launch sites during its calls */
 };
 
 static int ctx_enter(vfe_ctx* c) {
@@ -73,15 +75,17 @@ static int ctx_upload(vfe_ctx* c, int slot, const uint8_t* data, int rows, int c
     VFE_REQUIRE(step >= (size_t)cols * channels, "step smaller than a row");
     /* repack into the pinned staging buffer with the device pitch, then one contiguous copy.  Every successful call
      * ends with a stream synchronisation, but an entry point that returned an error may have left a copy from this
-     * buffer in flight: wait for it before the buffer is overwritten (free when the stream is idle). */
-    VFE_HIP(hipStreamSynchronize(c->stream));
+     * buffer in flight: wait for the last copy out of THIS buffer before it is overwritten (the other buffer's copy,
+     * e.g. the first image of vfe_klt_track, keeps running beside this repack). */
+    VFE_HIP(hipEventSynchronize(c->stage_ev[slot & 1]));
     uint8_t* hs = c->h_stage[slot & 1];
     const size_t row_bytes = (size_t)cols * channels;
     const size_t dpitch = channels == 1 ? (size_t)c->pitch[0] : (size_t)c->cfg.max_width * 3;
     /* in bands of rows: the copy engine moves a band while the host repacks the next one */
     uint8_t* dst = channels == 1 ? c->pyr[slot][0] : c->bgr;
     const size_t total = dpitch * (size_t)(rows - 1) + row_bytes;
-    const int nbands = total >= (1u << 20) ? 4 : total >= (1u << 18) ? 2 : 1;
+    int nbands = total >= (1u << 20) ? 4 : total >= (1u << 18) ? 2 : 1;
+    if (nbands > rows) nbands = rows; /* a band holds at least one row */
     for (int k = 0; k < nbands; k++) {
         const int r0 = (int)((long long)rows * k / nbands), r1 = (int)((long long)rows * (k + 1) / nbands);
         const size_t off = (size_t)r0 * dpitch, bytes = dpitch * (size_t)(r1 - r0 - 1) + row_bytes;
@@ -89,6 +93,7 @@ static int ctx_upload(vfe_ctx* c, int slot, const uint8_t* data, int rows, int c
         else for (int y = r0; y < r1; y++) memcpy(hs + (size_t)y * dpitch, data + (size_t)y * step, row_bytes);
         VFE_HIP(hipMemcpyAsync(dst + off, hs + off, bytes, hipMemcpyHostToDevice, c->stream));
     }
+    VFE_HIP(hipEventRecord(c->stage_ev[slot & 1], c->stream));
     if (channels != 1) {
         vfe_dimg s; s.data = c->bgr; s.width = cols; s.height = rows; s.pitch = (int)dpitch; s.batch = 1; s.frame_stride = dpitch * rows; s.border = 0;
         vfe_dimg g = ctx_level(c, slot, 0, cols, rows);
@@ -117,7 +122,9 @@ extern "C" void vfe_destroy(vfe_ctx* c) {
     (void)hipFree(c->f_ws);
     (void)hipFree(c->det_ws); (void)hipFree(c->det_pts); (void)hipFree(c->det_scores);
     (void)hipHostFree(c->h_stage[0]); (void)hipHostFree(c->h_stage[1]); (void)hipHostFree(c->h_io); (void)hipHostFree(c->h_small);
+    for (int s = 0; s < 2; s++) if (c->stage_ev[s]) (void)hipEventDestroy(c->stage_ev[s]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    vfe_prof_forget_owner(c);
     delete c;
 }
 
@@ -152,6 +159,7 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
     if (!c) { vfe_set_error("out of host memory"); return VFE_E_NOMEM; }
     memset(c, 0, sizeof(*c));
     c->cfg = *cfg;
+    c->opts.owner = c; c->opts.overlap = -1; c->opts.prof = -1;
 #define CTX_TRY(call)                                                           \
     do {                                                                        \
         hipError_t e_ = (call);                                                 \
@@ -162,6 +170,7 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
         }                                                                       \
     } while (0)
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int s = 0; s < 2; s++) CTX_TRY(hipEventCreateWithFlags(&c->stage_ev[s], hipEventDisableTiming));
     int lw = cfg->max_width, lh = cfg->max_height;
     for (int l = 0; l < cfg->pyramid_levels; l++) {
         const int bd = l > 0 ? VFE_LK_BORDER : 0;
@@ -211,6 +220,7 @@ extern "C" int vfe_create(const vfe_config* cfg, vfe_ctx** out) {
 extern "C" int vfe_set_f_rejection(vfe_ctx* c, double threshold, const double* camera4, const double* dist5, double virtual_focal) {
     int rc = ctx_enter(c);
     if (rc) return rc;
+    VfeCallScope call_scope(&c->opts);
     if (!(threshold > 0)) { c->f_thr = 0; return VFE_OK; }
     VFE_REQUIRE(c->cfg.max_features <= 2048, "the epipolar filter takes at most 2048 points: create the context with max_features <= 2048");
     VFE_REQUIRE(!camera4 || (dist5 && virtual_focal > 0 && camera4[0] != 0.0 && camera4[1] != 0.0), "camera4 needs dist5 and a virtual focal length");
@@ -228,6 +238,7 @@ extern "C" int vfe_set_f_rejection(vfe_ctx* c, double threshold, const double* c
 extern "C" int vfe_set_detector(vfe_ctx* c, int mode, int fast_threshold, int grid_x, int grid_y) {
     int rc = ctx_enter(c);
     if (rc) return rc;
+    VfeCallScope call_scope(&c->opts);
     VFE_REQUIRE(mode == VFE_DET_SHI_TOMASI || mode == VFE_DET_FAST_GRID, "mode must be VFE_DET_SHI_TOMASI or VFE_DET_FAST_GRID");
     if (mode == VFE_DET_FAST_GRID) {
         VFE_REQUIRE(fast_threshold >= 1 && fast_threshold <= 254, "fast_threshold must be 1..254");
@@ -255,6 +266,25 @@ static int ctx_det_buffers(vfe_ctx* c, int min_px) {
     return VFE_OK;
 }
 
+extern "C" int vfe_ctx_set_overlap(vfe_ctx* c, int mode) {
+    VFE_REQUIRE(c, "ctx is NULL");
+    VFE_REQUIRE(mode >= -1 && mode <= 1, "mode must be -1 (follow vfe_set_overlap), 0 or 1");
+    c->opts.overlap = mode;
+    return VFE_OK;
+}
+
+extern "C" int vfe_ctx_prof_enable(vfe_ctx* c, int mode) {
+    VFE_REQUIRE(c, "ctx is NULL");
+    VFE_REQUIRE(mode >= -1 && mode <= 1, "mode must be -1 (follow vfe_prof_enable), 0 or 1");
+    c->opts.prof = mode;
+    return VFE_OK;
+}
+
+extern "C" int vfe_ctx_prof_read(vfe_ctx* c, double* ms, long long* launches, int reset) {
+    VFE_REQUIRE(c, "ctx is NULL");
+    return vfe_prof_read_owner(c, ms, launches, reset);
+}
+
 extern "C" int vfe_set_equalize(vfe_ctx* c, int enable) {
     VFE_REQUIRE(c, "ctx is NULL");
     VFE_REQUIRE(enable == VFE_EQ_NONE || enable == VFE_EQ_HIST || enable == VFE_EQ_CLAHE, "mode must be 0, 1 or 2");
@@ -265,6 +295,7 @@ extern "C" int vfe_set_equalize(vfe_ctx* c, int enable) {
 extern "C" int vfe_reset(vfe_ctx* c) {
     int rc = ctx_enter(c);
     if (rc) return rc;
+    VfeCallScope call_scope(&c->opts);
     c->have_prev = 0; c->cur = 0; c->w = c->h = 0;
     VFE_HIP(hipMemsetAsync(c->n_pts, 0, sizeof(int), c->stream));
     VFE_HIP(hipStreamSynchronize(c->stream));
@@ -276,6 +307,7 @@ extern "C" int vfe_detect_shi_tomasi(vfe_ctx* c, const uint8_t* data, int rows, 
                                      float* corners_xy, int* n_out) {
     int rc = ctx_enter(c);
     if (rc) return rc;
+    VfeCallScope call_scope(&c->opts);
     VFE_REQUIRE(corners_xy && n_out, "NULL output");
     VFE_REQUIRE(max_corners > 0 && max_corners <= c->cfg.max_features, "max_corners exceeds the context's max_features");
     const int slot = c->cur ^ 1; /* scratch slot: does not disturb the stream's previous frame */
@@ -298,6 +330,7 @@ extern "C" int vfe_klt_track(vfe_ctx* c, const uint8_t* prev, const uint8_t* nex
                              int max_level, int max_iter, double eps, double min_eig_thr) {
     int rc = ctx_enter(c);
     if (rc) return rc;
+    VfeCallScope call_scope(&c->opts);
     VFE_REQUIRE(prev_pts && next_pts && status, "NULL point buffers");
     VFE_REQUIRE(n >= 0 && n <= c->cfg.max_features, "n exceeds the context's max_features");
     VFE_REQUIRE(max_level >= 0 && max_level < c->cfg.pyramid_levels, "max_level exceeds the context's pyramid_levels");
@@ -335,6 +368,7 @@ extern "C" int vfe_orb_extract(vfe_ctx* c, const uint8_t* data, int rows, int co
                                vfe_orb_kp* kps, uint8_t* desc, int cap, int* n_out) {
     int rc = ctx_enter(c);
     if (rc) return rc;
+    VfeCallScope call_scope(&c->opts);
     VFE_REQUIRE(kps && desc && n_out && cap > 0, "NULL output");
     VFE_REQUIRE(c->cfg.orb_levels > 0, "context was created without ORB (orb_levels = 0)");
     VFE_REQUIRE(nlevels >= 1 && nlevels <= c->cfg.orb_levels, "nlevels exceeds the context's orb_levels");
@@ -364,6 +398,7 @@ extern "C" int vfe_match_knn2(vfe_ctx* c, const uint8_t* query, int nq, const ui
                               float ratio, int* idx, int* dist, uint8_t* good) {
     int rc = ctx_enter(c);
     if (rc) return rc;
+    VfeCallScope call_scope(&c->opts);
     VFE_REQUIRE(query && idx && dist && nq > 0 && nt >= 0 && (nt == 0 || train), "NULL buffer or bad sizes");
     const size_t qb = align_up((size_t)nq * 32, 256), tb = align_up((size_t)nt * 32 + 32, 256);
     const size_t ob = align_up((size_t)nq * 2 * sizeof(int), 256), gb = align_up((size_t)nq, 256);
@@ -397,6 +432,7 @@ extern "C" int vfe_process_frame(vfe_ctx* c, const uint8_t* data, int rows, int 
     (void)timestamp_ns;
     int rc = ctx_enter(c);
     if (rc) return rc;
+    VfeCallScope call_scope(&c->opts);
     VFE_REQUIRE(max_corners > 0 && max_corners <= c->cfg.max_features, "max_corners exceeds the context's max_features");
     if (c->have_prev && (c->w != cols || c->h != rows)) c->have_prev = 0; /* size change restarts the stream */
     const int nxt = c->have_prev ? (c->cur ^ 1) : c->cur;
@@ -453,6 +489,7 @@ extern "C" int vfe_process_frame(vfe_ctx* c, const uint8_t* data, int rows, int 
 extern "C" int vfe_get_points(vfe_ctx* c, float* pts_xy, int cap, int* n_out) {
     int rc = ctx_enter(c);
     if (rc) return rc;
+    VfeCallScope call_scope(&c->opts);
     VFE_REQUIRE(pts_xy && n_out && cap >= 0, "NULL output");
     VFE_HIP(hipMemcpyAsync(c->h_small, c->n_pts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VFE_HIP(hipMemcpyAsync(c->h_io, c->pts, (size_t)c->cfg.max_features * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -369,12 +369,13 @@ __global__ __launch_bounds__(1024) void k_fast_scan_stream(FastSet S, const uint
 static int fast_set_geometry(FastSet& S, int batch) {
     /* band height 9k - 8 (whole turns of the unrolled row loop); the tallest that still gives every SIMD several items */
     static const int heights[5] = {64, 37, 28, 19, 10};
-    int band_h = 13;
+    int band_h = heights[4]; /* small sets: the shortest band that is still a whole number of turns */
     for (int i = 0; i < 5; i++) {
         long long items = 0;
         for (int l = 0; l < S.n; l++) items += (long long)div_up(S.img[l].w, FS_OUT) * div_up(S.img[l].h, heights[i]) * batch;
         if (items >= 12288) { band_h = heights[i]; break; }
     }
+    if ((band_h + 8) % FQ_PERIOD != 0) { vfe_set_error("FAST: band height %d is not a whole number of row-loop turns", band_h); return VFE_E_INVALID; }
     S.band_h = band_h;
     unsigned long long items = 0, segs = 0;
     for (int l = 0; l < S.n; l++) {

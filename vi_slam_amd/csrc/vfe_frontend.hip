@@ -167,12 +167,16 @@ extern "C" size_t vfe_frontend_workspace(int width, int height, int batch, int m
 }
 
 /* helper stream + fork/join events, one set per host thread and device, created on first use */
-AuxStream* vfe_aux_stream() {
+AuxStream* vfe_aux_stream(hipStream_t caller) {
     static thread_local AuxStream pool[32];
     static thread_local bool made[32];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
     if (!made[dev]) {
+        /* streams and events cannot be created while the caller's stream is being captured into a graph: such a call
+         * runs on the caller's stream alone (the helper exists from the first call outside a capture on) */
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (caller && (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return nullptr;
         AuxStream a;
         /* lowest priority: what runs here (the detector's image-only half) fills the chip beside the caller's stream, whose
          * short dependent launches (the small pyramid levels in front of the tracker) must not queue behind its long waves */
@@ -192,6 +196,7 @@ AuxStream* vfe_aux_stream() {
  * the kernels one at a time). */
 static std::atomic<int> g_overlap{-1}; /* -1: not set yet, take the environment's word */
 bool vfe_overlap_on() {
+    if (t_vfe_call && t_vfe_call->overlap >= 0) return t_vfe_call->overlap != 0; /* the calling context's own choice */
     int m = g_overlap.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("VFE_OVERLAP");
@@ -298,7 +303,7 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
      * pyramids, so they run side by side -- the first half on a helper stream forked from the caller's stream here and
      * joined before the selection. */
     hipStream_t st = (hipStream_t)stream;
-    AuxStream* aux = vfe_overlap_on() ? vfe_aux_stream() : nullptr;
+    AuxStream* aux = vfe_overlap_on() ? vfe_aux_stream(st) : nullptr;
     ForkGuard guard{nullptr, st, false};
     const EigBeside beside = eig_beside_policy(w, h, batch);
     const bool fork_late = beside.after_pyramid;

@@ -30,7 +30,12 @@ public:
     int getTrackedFeatureCount() const override { return trackedFeatureCount_.load(); }
     std::string getFrontEndError() const override;
     bool getLastFrameStats(FrontEndFrameStats& out) const override;
+    void enableStageTiming(bool on) override;
     bool isReadyForVision() const;
+    /* `enable_gpu` / `gpu_device` of the configuration (every adapter reads them): with the GPU off the adapter keeps its
+     * lifecycle, IMU handling and status logic and hands no image to the front-end -- there is no CPU fallback */
+    bool gpuEnabled() const { return gpuEnabled_; }
+    int gpuDevice() const { return frontEnd_.device(); }
 
 protected:
     struct Traits {
@@ -79,6 +84,8 @@ private:
     std::atomic<bool> initialized_{false}, calibrated_{false};
     std::atomic<int> trackedFeatureCount_{0};
     bool imuInitialized_ = false;
+    bool gpuEnabled_ = true, gpuOffLogged_ = false;
+    int pendingDevice_ = -1, pendingOverlap_ = -1;
     int frameTracked_ = 0, frameDetected_ = 0, frameTotal_ = 0; /* set by feedImage through reportFrame */
     mutable std::mutex frameStatsMutex_;
     FrontEndFrameStats lastFrame_;

@@ -17,7 +17,17 @@ public:
     GpuFrontEnd(const GpuFrontEnd&) = delete;
     GpuFrontEnd& operator=(const GpuFrontEnd&) = delete;
 
-    void configure(int maxFeatures, int pyramidLevels, int winSize, int orbLevels, int device = 0);
+    void configure(int maxFeatures, int pyramidLevels, int winSize, int orbLevels);
+    /* HIP device the context lives on (`gpu_device`); a change takes effect with the next frame */
+    void setDevice(int device);
+    int device() const { return cfg_.device; }
+    /* per-stage GPU times of this context's launches (HIP events around each kernel); readStageTimes hands out and
+     * clears what has accumulated since the last read, in milliseconds per stage */
+    void setStageTiming(bool on);
+    bool stageTiming() const { return stageTiming_; }
+    bool readStageTimes(double* ms, int count);
+    /* the detector's image-only pass beside pyramid + tracker on a helper stream: 1 on, 0 off, -1 the library's default */
+    void setOverlap(int mode);
     /* histogram-equalise every frame before it is used (config/vins_mono.yaml:104 `equalize`) */
     void setEqualize(bool on);
     /* VFE_EQ_NONE / VFE_EQ_HIST / VFE_EQ_CLAHE (`histogram_method`, docs/reference/15_openvins_smartphone_config.md:111) */
@@ -46,6 +56,8 @@ private:
     int equalize_ = 0;
     double fThr_ = 0, fCam_[4] = {0, 0, 0, 0}, fDist_[5] = {0, 0, 0, 0, 0}, fFocal_ = 460.0;
     bool fHaveCam_ = false;
+    bool stageTiming_ = false;
+    int overlap_ = -1;
     bool detFast_ = false;
     int detThr_ = 20, detGx_ = 5, detGy_ = 5;
     std::string error_;

@@ -46,8 +46,8 @@ public:
     void setFrontEndStatsCallback(FrontEndStatsCallback callback);
     const FrontEndStats& frontEndStats() const { return stats_; }
     FrontEndStats& frontEndStats() { return stats_; }
-    /* per-stage GPU times in every FrontEndFrameStats (HIP events around each kernel; process-wide switch of the GPU
-     * library, so use it with one engine per process) */
+    /* per-stage GPU times in every FrontEndFrameStats (HIP events around each kernel of this engine's own front-end
+     * context: engines in one process do not see or switch each other's timing); survives selectFramework */
     void enableStageTiming(bool on);
     ISLAMFramework* framework() { return framework_.get(); }
 

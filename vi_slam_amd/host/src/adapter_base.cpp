@@ -30,18 +30,27 @@ bool AdapterBase::parseConfigFile(const std::string& path) {
     std::ifstream file(path);
     if (!file.is_open()) return false;
     std::string line, section;
+    gpuEnabled_ = true; gpuOffLogged_ = false; pendingDevice_ = -1; pendingOverlap_ = -1;
     while (std::getline(file, line)) {
         if (line.empty() || line[0] == '#') continue;
         if (isSectionHeader(line, section)) continue;
         std::string key, value;
         if (!splitKeyValue(line, key, value)) continue;
         try {
+            /* keys every adapter understands (the reference's only GPU key, `processing.enable_gpu` of
+             * config/pc_client_config.yaml:15, is read by nothing there) */
+            if (key == "enable_gpu" || key == "processing.enable_gpu") { gpuEnabled_ = parseBool(value); continue; }
+            if (key == "gpu_device") { pendingDevice_ = std::stoi(value); continue; }
+            if (key == "gpu_overlap") { pendingOverlap_ = parseBool(value) ? 1 : 0; continue; }
             configKey(section, key, value);
         } catch (const std::exception& e) {
             LOG_WARN(traits_.name, "ignoring malformed value for '%s': %s", key.c_str(), e.what());
         }
     }
     configDone();
+    /* after configDone: the adapters (re)configure their front-end there */
+    frontEnd_.setDevice(pendingDevice_ < 0 ? 0 : pendingDevice_);
+    frontEnd_.setOverlap(pendingOverlap_);
     return true;
 }
 
@@ -108,6 +117,11 @@ void AdapterBase::processImage(const ImageView& image, int64_t timestampNs) {
         }
     }
     frameTracked_ = frameDetected_ = frameTotal_ = 0;
+    if (!gpuEnabled_) {
+        if (!gpuOffLogged_) { LOG_WARN(traits_.name, "enable_gpu is false: images are accepted and not processed (no CPU fallback)"); gpuOffLogged_ = true; }
+        lastImageTimestampNs_ = timestampNs;
+        return;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     const int tracked = feedImage(image, timestampNs, since);
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -132,8 +146,16 @@ void AdapterBase::processImage(const ImageView& image, int64_t timestampNs) {
         lastFrame_.total = tracked >= 0 ? (frameTotal_ ? frameTotal_ : tracked) : 0;
         lastFrame_.latencyUs = us;
         lastFrame_.status = status_.load();
+        static_assert(kFrontEndStages == VFE_K_COUNT, "FrontEndFrameStats::stageUs has one slot per timing slot of the GPU library");
+        double ms[kFrontEndStages];
+        if (frontEnd_.stageTiming() && frontEnd_.readStageTimes(ms, kFrontEndStages)) {
+            lastFrame_.haveStages = true;
+            for (int i = 0; i < kFrontEndStages; i++) lastFrame_.stageUs[i] = ms[i] * 1e3;
+        }
     }
 }
+
+void AdapterBase::enableStageTiming(bool on) { frontEnd_.setStageTiming(on); }
 
 bool AdapterBase::getLastFrameStats(FrontEndFrameStats& out) const {
     std::lock_guard<std::mutex> lock(frameStatsMutex_);

@@ -5,13 +5,40 @@ namespace vi_slam {
 
 GpuFrontEnd::~GpuFrontEnd() { release(); }
 
-void GpuFrontEnd::configure(int maxFeatures, int pyramidLevels, int winSize, int orbLevels, int device) {
+void GpuFrontEnd::configure(int maxFeatures, int pyramidLevels, int winSize, int orbLevels) {
     release();
-    cfg_.device = device;
     cfg_.max_features = maxFeatures > 0 ? maxFeatures : 1;
     cfg_.pyramid_levels = pyramidLevels < 1 ? 1 : (pyramidLevels > 8 ? 8 : pyramidLevels);
     cfg_.win_size = winSize;
     cfg_.orb_levels = orbLevels;
+}
+
+void GpuFrontEnd::setDevice(int device) {
+    if (device == cfg_.device) return;
+    release();
+    cfg_.device = device;
+}
+
+void GpuFrontEnd::setStageTiming(bool on) {
+    stageTiming_ = on;
+    if (ctx_) {
+        (void)vfe_ctx_prof_enable(ctx_, on ? 1 : -1);
+        (void)vfe_ctx_prof_read(ctx_, nullptr, nullptr, 1);
+    }
+}
+
+bool GpuFrontEnd::readStageTimes(double* ms, int count) {
+    static_assert(VFE_K_COUNT >= 1, "timing slots");
+    if (!ctx_ || !stageTiming_ || !ms) return false;
+    double all[VFE_K_COUNT];
+    if (vfe_ctx_prof_read(ctx_, all, nullptr, 1) != VFE_OK) return false;
+    for (int i = 0; i < count; i++) ms[i] = i < VFE_K_COUNT ? all[i] : 0.0;
+    return true;
+}
+
+void GpuFrontEnd::setOverlap(int mode) {
+    overlap_ = mode < 0 ? -1 : (mode ? 1 : 0);
+    if (ctx_) (void)vfe_ctx_set_overlap(ctx_, overlap_);
 }
 
 void GpuFrontEnd::setEqualize(bool on) { setEqualizeMode(on ? VFE_EQ_HIST : VFE_EQ_NONE); }
@@ -75,6 +102,8 @@ bool GpuFrontEnd::ensure(const ImageView& img) {
         const int rcF = vfe_set_f_rejection(ctx_, fThr_, fHaveCam_ ? fCam_ : nullptr, fHaveCam_ ? fDist_ : nullptr, fFocal_);
         if (rcF != VFE_OK) { release(); return fail(rcF); }
     }
+    (void)vfe_ctx_set_overlap(ctx_, overlap_);
+    if (stageTiming_) (void)vfe_ctx_prof_enable(ctx_, 1);
     error_.clear();
     return true;
 }

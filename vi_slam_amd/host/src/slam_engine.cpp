@@ -1,6 +1,5 @@
 #include "slam/slam_engine.hpp"
 #include "common/logging.hpp"
-#include "vfe.h"
 #include "slam/adapters/basalt_adapter.hpp"
 #include "slam/adapters/openvins_adapter.hpp"
 #include "slam/adapters/orbslam3_adapter.hpp"
@@ -24,11 +23,14 @@ std::unique_ptr<ISLAMFramework> SLAMEngine::createFramework(SLAMFrameworkType ty
 
 bool SLAMEngine::selectFramework(SLAMFrameworkType type) {
     std::lock_guard<std::mutex> lock(frameworkMutex_);
+    /* already on this framework: nothing to tear down, and it stays initialised (reference src/slam/slam_engine.cpp:25-29) */
+    if (framework_ && currentType_ == type) return true;
     if (framework_) framework_->shutdown();
     framework_ = createFramework(type);
     if (!framework_) return false;
     currentType_ = type;
     initialized_ = false;
+    if (stageTiming_) framework_->enableStageTiming(true);
     return true;
 }
 
@@ -42,6 +44,7 @@ bool SLAMEngine::initialize(const std::string& configPath) {
     if (!framework_) {
         framework_ = createFramework(currentType_); /* default framework when none was selected */
         if (!framework_) return false;
+        if (stageTiming_) framework_->enableStageTiming(true);
     }
     if (!framework_->initialize(configPath)) {
         LOG_ERROR("SLAMEngine", "Framework initialization failed");
@@ -71,14 +74,6 @@ void SLAMEngine::processImage(const ImageView& image, int64_t timestampNs) {
      * front-end and leaves no record */
     FrontEndFrameStats fs;
     if (framework_->getLastFrameStats(fs) && (!hadFrame || fs.frameIndex != before.frameIndex)) {
-        if (stageTiming_) {
-            double ms[VFE_K_COUNT];
-            long long n[VFE_K_COUNT];
-            if (vfe_prof_read(ms, n, 1) == VFE_OK) {
-                fs.haveStages = true;
-                for (int i = 0; i < kFrontEndStages; i++) fs.stageUs[i] = ms[i] * 1e3;
-            }
-        }
         stats_.record(fs);
         std::lock_guard<std::mutex> cb(callbackMutex_);
         if (statsCallback_) statsCallback_(fs);
@@ -93,8 +88,7 @@ void SLAMEngine::setFrontEndStatsCallback(FrontEndStatsCallback callback) {
 void SLAMEngine::enableStageTiming(bool on) {
     std::lock_guard<std::mutex> lock(frameworkMutex_);
     stageTiming_ = on;
-    (void)vfe_prof_enable(on ? 1 : 0);
-    if (on) (void)vfe_prof_read(nullptr, nullptr, 1);
+    if (framework_) framework_->enableStageTiming(on);
 }
 
 void SLAMEngine::processIMU(const IMUSample& imu) {
