@@ -558,6 +558,61 @@ def run_reloc_leg(rk, steps, warmup, counters, force_collective=False):
     return out
 
 
+def run_cpp_batch_host_leg(host, nb, device, steps, warmup):
+    """configs[3]'s per-GPU share through the C++ host (vi_slam::BatchFrontEnd: one host thread per GPU, pinned staging,
+    upload of set i + 1 beside the step on set i, results collected one submission late): (i) frames written in place into
+    the pinned staging memory, as a decoder would deliver them, (ii) frames in pageable caller memory, repacked by the
+    host's copy threads.  Every frame crosses the link; compare with streams64.h2d_inclusive (the Python loop)."""
+    from vi_slam_amd import engine as eng
+    out = {}
+    nf = len(host)
+    order = list(range(1, nf)) + list(range(nf - 2, -1, -1))
+    threads = max(1, min(8, host_cores() - 2))
+    for name in ("staged", "caller_memory"):
+        fe = eng.BatchFrontEnd(W, H, nb, max_features=NFEAT, levels=LEVELS, win=WIN, quality=QUALITY, min_distance=MIN_DIST,
+                               devices=(device,), copy_threads=threads)
+        views = [[host[t][b] for b in range(nb)] for t in range(nf)]
+
+        def put(i):
+            fr = views[order[i % len(order)]] if i else views[0]
+            if name == "staged":
+                for b in range(nb):  # the memcpy a producer would not need: it would write here directly
+                    fe.staging(b)[:, :W] = fr[b]
+                return fe.submit_staged(i)
+            return fe.submit(fr, i)
+
+        prev = put(0)
+        for i in range(1, warmup + 1):
+            t = put(i)
+            fe.wait(prev, points=False)
+            prev = t
+        t0 = time.perf_counter()
+        fill = 0.0
+        for i in range(warmup + 1, warmup + 1 + steps):
+            if name == "staged":  # the in-place fill stands for the producer's own work: timed apart and taken out
+                f0 = time.perf_counter()
+                fr = views[order[i % len(order)]]
+                for b in range(nb):
+                    fe.staging(b)[:, :W] = fr[b]
+                fill += time.perf_counter() - f0
+                t = fe.submit_staged(i)
+            else:
+                t = put(i)
+            tot, trk, _ = fe.wait(prev, points=False)
+            prev = t
+        tot, trk, _ = fe.wait(prev, points=False)
+        el = time.perf_counter() - t0
+        fe.close()
+        net = el - fill
+        out[name] = {"value": nb * steps / net, "unit": "frames/s", "steps": steps, "ms_per_step": net / steps * 1e3,
+                     "streams": nb, "copy_threads": threads, "mean_points": float(np.mean(tot)), "mean_tracked": float(np.mean(trk))}
+        if name == "staged":
+            out[name]["producer_fill_ms_per_step_excluded"] = fill / steps * 1e3
+    out["what"] = ("vi_slam::BatchFrontEnd (C++ host, libvi_slam_amd.so) driven through its C view: per step one set of "
+                   f"{nb} 1920x1080 frames uploaded from host memory and stepped; no track-loss model (the scene loses few tracks)")
+    return out
+
+
 def run_single_stream_leg(frames_host):
     """configs[0] / [1] through the host-pointer API the adapters call (vfe_process_frame: upload + pyramid + KLT + refill,
     one synchronisation per call), one live stream on this rank's GPU."""
@@ -597,7 +652,7 @@ def main():
     ap.add_argument("--overlap", choices=["on", "off"], default="on",
                     help="on (the library's default): the detector's eigenvalue pass runs beside pyramid + tracker on a helper "
                          "stream, and per-kernel durations come from a separate one-stream pass; off: everything on one stream")
-    ap.add_argument("--legs", default="main,streams64,orb_match,reloc,single_stream",
+    ap.add_argument("--legs", default="main,streams64,orb_match,reloc,single_stream,cpp_host",
                     help="comma-separated legs to run (main always runs)")
     ap.add_argument("--orb-batch", type=int, default=64, help="streams per GPU in the orb_match leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -723,6 +778,9 @@ def main():
         log("single_stream / cpu_baseline legs")
         if "single_stream" in legs:
             out["single_stream"] = run_single_stream_leg(frames_host_1080)
+        if "cpp_host" in legs and world == 1:
+            log("cpp_host leg (vi_slam::BatchFrontEnd)")
+            out["cpp_batch_host"] = run_cpp_batch_host_leg(host, min(64, B), local_rank, max(20, args.steps // 10), 3)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(host, args.loss, n_distinct)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]

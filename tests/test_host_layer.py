@@ -148,3 +148,12 @@ def test_first_real_frame_without_gpu_fails_loudly(tmp_path):
     assert e.tracked_count() == 0
     assert "device" in e.frontend_error().lower() or "hip" in e.frontend_error().lower()
     e.close()
+
+
+def test_batch_frontend_refuses_without_a_gpu():
+    """vi_slam::BatchFrontEnd has no CPU fallback: on a machine without a GPU open() fails and says why."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("this machine has a GPU")
+    with pytest.raises(RuntimeError, match="no usable GPU|no HIP device"):
+        eng.BatchFrontEnd(640, 480, 4)

@@ -48,6 +48,19 @@ def lib():
             ("vis_engine_stage_us", [C.c_void_p, C.POINTER(C.c_double)], C.c_int),
             ("vis_engine_stats_json", [C.c_void_p], C.c_char_p),
             ("vis_engine_reset_latency_stats", [C.c_void_p], None),
+            ("vis_batch_open", [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int),
+                                C.c_int, C.c_int], C.c_void_p),
+            ("vis_batch_close", [C.c_void_p], None),
+            ("vis_batch_is_open", [C.c_void_p], C.c_int),
+            ("vis_batch_shards", [C.c_void_p], C.c_int),
+            ("vis_batch_error", [C.c_void_p], C.c_char_p),
+            ("vis_batch_submit", [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_int64], C.c_int),
+            ("vis_batch_staging", [C.c_void_p, C.c_int], C.c_void_p),
+            ("vis_batch_staging_pitch", [C.c_void_p], C.c_size_t),
+            ("vis_batch_submit_staged", [C.c_void_p, C.c_int64], C.c_int),
+            ("vis_batch_wait", [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+            ("vis_batch_points", [C.c_void_p, C.c_int, C.c_void_p, C.c_int], C.c_int),
+            ("vis_batch_reset", [C.c_void_p], C.c_int),
         ]:
             fn = getattr(L, name)
             fn.argtypes = args
@@ -192,3 +205,73 @@ def run_streaming(engine, frames, imu_per_frame=10, frame_dt_ns=100_000_000, t0_
         lat.append((time.perf_counter() - s) * 1e3)
         counts.append(engine.tracked_count())
     return lat, counts
+
+
+class BatchFrontEnd:
+    """vi_slam::BatchFrontEnd (C++): `streams` independent live streams per call, split over `devices` in contiguous
+    blocks, one host thread per block; frames are numpy uint8 arrays [H, W] (or one [streams, H, W] array)."""
+
+    def __init__(self, width, height, streams, max_features=1000, levels=4, win=21, quality=0.01, min_distance=20.0,
+                 devices=(), copy_threads=4):
+        dev = (C.c_int * max(1, len(devices)))(*devices)
+        self.width, self.height, self.streams, self.cap = width, height, streams, max_features
+        self._h = C.c_void_p(lib().vis_batch_open(width, height, streams, max_features, levels, win, quality, min_distance,
+                                                  dev, len(devices), copy_threads))
+        if not lib().vis_batch_is_open(self._h):
+            msg = lib().vis_batch_error(self._h).decode()
+            self.close()
+            raise RuntimeError(f"BatchFrontEnd: {msg}")
+
+    def close(self):
+        if self._h:
+            lib().vis_batch_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def shards(self):
+        return lib().vis_batch_shards(self._h)
+
+    def submit(self, frames, ts=0):
+        """frames: sequence of `streams` C-contiguous-row uint8 arrays of one row step; -> ticket."""
+        step = frames[0].strides[0]
+        ptrs = (C.c_void_p * self.streams)(*[f.ctypes.data for f in frames])
+        t = lib().vis_batch_submit(self._h, ptrs, len(frames), step, ts)
+        if t < 0:
+            raise RuntimeError(lib().vis_batch_error(self._h).decode())
+        return t
+
+    def staging(self, stream):
+        """numpy view [H, pitch] of the pinned staging memory of `stream` for the next submit_staged()."""
+        pitch = lib().vis_batch_staging_pitch(self._h)
+        p = lib().vis_batch_staging(self._h, stream)
+        return np.ctypeslib.as_array((C.c_uint8 * (pitch * self.height)).from_address(p)).reshape(self.height, pitch)
+
+    def submit_staged(self, ts=0):
+        t = lib().vis_batch_submit_staged(self._h, ts)
+        if t < 0:
+            raise RuntimeError(lib().vis_batch_error(self._h).decode())
+        return t
+
+    def wait(self, ticket, points=True):
+        """-> (totals [streams], tracked [streams], list of [n, 2] float32 arrays or None)."""
+        tot = (C.c_int * self.streams)()
+        trk = (C.c_int * self.streams)()
+        if not lib().vis_batch_wait(self._h, ticket, tot, trk):
+            raise RuntimeError(lib().vis_batch_error(self._h).decode())
+        pts = None
+        if points:
+            pts = []
+            for s in range(self.streams):
+                a = np.empty((max(tot[s], 1), 2), np.float32)
+                n = lib().vis_batch_points(self._h, s, a.ctypes.data, tot[s])
+                pts.append(a[:n])
+        return np.array(tot[:]), np.array(trk[:]), pts
+
+    def reset(self):
+        return bool(lib().vis_batch_reset(self._h))

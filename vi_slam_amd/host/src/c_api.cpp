@@ -1,5 +1,6 @@
 /* Flat C view of SLAMEngine for non-C++ harnesses (the Python streaming harness and tests). */
 #include "slam/slam_engine.hpp"
+#include "slam/batch_frontend.hpp"
 #include "slam/adapters/openvins_adapter.hpp"
 #include "slam/adapters/basalt_adapter.hpp"
 #include "slam/adapters/orbslam3_adapter.hpp"
@@ -149,5 +150,66 @@ int vis_engine_config_value(void* p, const char* key, double* out) {
     }
     return 0;
 }
+
+/* ---- BatchFrontEnd: many streams per call ------------------------------------------------------------------------- */
+namespace {
+struct BatchHandle {
+    BatchFrontEnd fe;
+    std::vector<BatchStreamResult> res;
+    std::vector<ImageView> views;
+    std::string err;
+};
+}  // namespace
+
+/* devices: `ndev` HIP ordinals (one shard of streams each), or ndev = 0 for device 0 */
+void* vis_batch_open(int width, int height, int streams, int max_features, int levels, int win, double quality, double min_distance,
+                     const int* devices, int ndev, int copy_threads) {
+    BatchHandle* h = new BatchHandle;
+    BatchFrontEndConfig c;
+    c.width = width; c.height = height; c.streams = streams; c.maxFeatures = max_features; c.pyramidLevels = levels; c.winSize = win;
+    c.quality = quality; c.minDistance = min_distance; c.copyThreads = copy_threads;
+    for (int i = 0; i < ndev; i++) c.devices.push_back(devices[i]);
+    (void)h->fe.open(c); /* a failed open is reported by vis_batch_is_open / vis_batch_error */
+    return h;
+}
+void vis_batch_close(void* p) { delete static_cast<BatchHandle*>(p); }
+int vis_batch_is_open(void* p) { return static_cast<BatchHandle*>(p)->fe.isOpen() ? 1 : 0; }
+int vis_batch_shards(void* p) { return static_cast<BatchHandle*>(p)->fe.shards(); }
+const char* vis_batch_error(void* p) {
+    BatchHandle* h = static_cast<BatchHandle*>(p);
+    h->err = h->fe.lastError();
+    return h->err.c_str();
+}
+/* frames: `count` pointers to 8-bit gray images of the configured size, `step` bytes per row each */
+int vis_batch_submit(void* p, const uint8_t* const* frames, int count, size_t step, int64_t ts) {
+    BatchHandle* h = static_cast<BatchHandle*>(p);
+    const BatchFrontEndConfig& c = h->fe.config();
+    h->views.clear();
+    for (int i = 0; i < count; i++) h->views.emplace_back(frames[i], c.height, c.width, step, 1);
+    return h->fe.submit(h->views.data(), count, ts);
+}
+uint8_t* vis_batch_staging(void* p, int stream) { return static_cast<BatchHandle*>(p)->fe.staging(stream); }
+size_t vis_batch_staging_pitch(void* p) { return static_cast<BatchHandle*>(p)->fe.stagingPitch(); }
+int vis_batch_submit_staged(void* p, int64_t ts) { return static_cast<BatchHandle*>(p)->fe.submitStaged(ts); }
+/* totals / tracked: one int per stream (may be NULL); returns 1 when the ticket's results are in */
+int vis_batch_wait(void* p, int ticket, int* totals, int* tracked) {
+    BatchHandle* h = static_cast<BatchHandle*>(p);
+    if (!h->fe.wait(ticket, h->res)) return 0;
+    for (size_t i = 0; i < h->res.size(); i++) {
+        if (totals) totals[i] = h->res[i].total;
+        if (tracked) tracked[i] = h->res[i].tracked;
+    }
+    return 1;
+}
+/* points of `stream` from the last successful vis_batch_wait: copies up to cap (x, y) pairs, returns the count */
+int vis_batch_points(void* p, int stream, float* xy, int cap) {
+    BatchHandle* h = static_cast<BatchHandle*>(p);
+    if (stream < 0 || (size_t)stream >= h->res.size()) return -1;
+    int n = h->res[stream].total;
+    if (n > cap) n = cap;
+    std::memcpy(xy, h->res[stream].xy, (size_t)n * 2 * sizeof(float));
+    return n;
+}
+int vis_batch_reset(void* p) { return static_cast<BatchHandle*>(p)->fe.reset() ? 1 : 0; }
 
 }  // extern "C"
