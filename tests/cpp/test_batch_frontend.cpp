@@ -8,6 +8,7 @@
 #include "slam/slam_engine.hpp"
 #include "slam/adapters/vins_mono_adapter.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -37,7 +38,7 @@ int main() {
     cfg.copyThreads = 2;
     BatchFrontEnd batch;
     CHECK(batch.open(cfg));
-    CHECK(batch.shards() == 2);
+    CHECK(batch.shards() == (int)cfg.devices.size());
     {
         BatchFrontEndConfig bad = cfg;
         bad.devices = {0, 63};

@@ -34,7 +34,8 @@ int main() {
         if (!s.ok) failed++;
         if (s.latencyUs > maxLatencyUs) maxLatencyUs = s.latencyUs;
     });
-    engine.setStatusCallback([&](TrackingStatus s) { if (s == TrackingStatus::LOST) lostEvents++; });
+    TrackingStatus lastStatus = TrackingStatus::UNINITIALIZED;
+    engine.setStatusCallback([&](TrackingStatus s) { if (s == TrackingStatus::LOST && lastStatus != s) lostEvents++; lastStatus = s; });
     CHECK(engine.selectFramework(SLAMFrameworkType::VINS_MONO));
     CHECK(engine.initialize("/tmp/vsa_soak_cfg.yaml"));
     CHECK(engine.loadCalibration("/tmp/vsa_soak_calib.yaml"));
@@ -50,7 +51,7 @@ int main() {
             fed++;
         }
         CHECK(hipMemGetInfo(&freeNow, &total) == hipSuccess);
-        if (fed == 100) freeAtStart = freeNow;
+        if (fed == 1000) freeAtStart = freeNow; /* past the warm-up: the runtime's own pools (signals, kernel arguments) have grown to size */
         if (std::chrono::duration<double>(Clock::now() - lastReport).count() >= 60.0) {
             std::printf("[soak] %zu frames, %zu failed, avg %.1f us, p99 %.1f us\n", fed, failed,
                         engine.frontEndStats().getAverageLatencyUs(), engine.frontEndStats().getP99LatencyUs());
@@ -67,7 +68,8 @@ int main() {
     CHECK(failed == 0);
     CHECK(engine.getFrontEndError().empty());
     CHECK(engine.frontEndStats().getAverageLatencyUs() < 100000.0); /* the reference's 100 ms average bound */
-    CHECK(freeNow == freeAtStart);           /* nothing allocated per frame */
+    CHECK(fed > 2000);
+    CHECK(freeNow == freeAtStart);           /* nothing allocated per frame: no change between frame 1000 and the last one */
     CHECK(engine.getTrackedFeatureCount() > 40);
     std::printf("soak: all checks passed\n");
     return 0;

@@ -178,11 +178,13 @@ AuxStream* vfe_aux_stream(hipStream_t caller) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (caller && (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return nullptr;
         AuxStream a;
-        /* lowest priority: what runs here (the detector's image-only half) fills the chip beside the caller's stream, whose
-         * short dependent launches (the small pyramid levels in front of the tracker) must not queue behind its long waves */
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
-        if (hipStreamCreateWithPriority(&a.s, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+        /* Same priority as the caller's streams.  A lower one looks attractive (freed wave slots go to the caller's short
+         * dependent launches first, worth about 1 % of a step) but is a priority inversion waiting to happen: the caller's
+         * stream sits at a barrier until the helper's kernel has run, and when a process keeps more streams busy than the
+         * device has hardware queues, the scheduler does not get round to a lower-priority queue while higher-priority
+         * ones still hold packets -- blocked ones included.  Seen as a hang with six single-stream contexts on one thread
+         * and a batched pipeline on another. */
+        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
         pool[dev] = a; made[dev] = true;

@@ -3,6 +3,8 @@
 #include "vfe.h"
 #include <hip/hip_runtime_api.h>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -18,6 +20,16 @@ constexpr int kSlots = 3;      /* staging / frame / result slots per stream: set
 constexpr int kMaxLevels = 8;
 
 size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/* VSA_BATCH_TRACE=1 in the environment: one line per stage on stderr (where does a stalled pipeline stand) */
+bool traceOn() {
+    static const bool on = [] { const char* e = std::getenv("VSA_BATCH_TRACE"); return e && *e && *e != '0'; }();
+    return on;
+}
+#define BF_TRACE(...)                                                     \
+    do {                                                                  \
+        if (traceOn()) { std::fprintf(stderr, "[batch] " __VA_ARGS__); std::fputc('\n', stderr); std::fflush(stderr); } \
+    } while (0)
 
 /* n persistent threads; run(count, fn) calls fn(i) for every i in [0, count) on them and returns when all are done */
 class CopyPool {
@@ -211,12 +223,15 @@ struct BatchFrontEnd::Impl {
             if (im.step == pitch0) std::memcpy(dst + (size_t)r0 * pitch0, im.data + (size_t)r0 * im.step, (size_t)(r1 - r0) * pitch0);
             else for (int y = r0; y < r1; y++) std::memcpy(dst + (size_t)y * pitch0, im.data + (size_t)y * im.step, (size_t)cfg.width);
         };
+        BF_TRACE("shard %d-%d: repack into slot %d", s.s0, s.s1, slot);
         s.pool->run(s.nb * pieces, fn);
+        BF_TRACE("shard %d-%d: repack done", s.s0, s.s1);
     }
 
     /* upload of the staging slot + the step on it; everything is only enqueued */
     bool shardSubmit(Shard& s, int ticket, bool first) {
         const int slot = ticket % kSlots;
+        BF_TRACE("shard %d-%d: submit ticket %d (first %d)", s.s0, s.s1, ticket, (int)first);
         BF_HIP(s, hipSetDevice(s.dev));
         /* the device frame of this slot was the previous image of the step two tickets ago */
         if (ticket >= 2) BF_HIP(s, hipStreamWaitEvent(s.copy, s.stepDone[(ticket - 2) % kSlots], 0));
@@ -243,6 +258,7 @@ struct BatchFrontEnd::Impl {
         BF_HIP(s, hipMemcpyAsync(s.resPts[slot], s.pts, (size_t)s.nb * cfg.maxFeatures * 2 * sizeof(float), hipMemcpyDeviceToHost, s.compute));
         BF_HIP(s, hipMemcpyAsync(s.resN[slot], s.counts, (size_t)2 * s.nb * sizeof(int), hipMemcpyDeviceToHost, s.compute));
         BF_HIP(s, hipEventRecord(s.resDone[slot], s.compute));
+        BF_TRACE("shard %d-%d: ticket %d enqueued", s.s0, s.s1, ticket);
         return true;
     }
 
@@ -393,8 +409,10 @@ bool BatchFrontEnd::wait(int ticket, std::vector<BatchStreamResult>& out) {
         return false;
     }
     const int slot = ticket % kSlots;
-    if (!m.onAll([slot](Shard& s) {
+    if (!m.onAll([slot, ticket](Shard& s) {
+            BF_TRACE("shard %d-%d: wait for ticket %d", s.s0, s.s1, ticket);
             const hipError_t e = hipEventSynchronize(s.resDone[slot]);
+            BF_TRACE("shard %d-%d: ticket %d done (%d)", s.s0, s.s1, ticket, (int)e);
             return e == hipSuccess ? true : hipFail(s, e, "hipEventSynchronize(results)");
         })) return false;
     out.resize(m.cfg.streams);
