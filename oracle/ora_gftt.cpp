@@ -51,12 +51,30 @@ extern "C" void ora_min_eigen_map(const uint8_t* img, int w, int h, int step, fl
         }
 }
 
+static int select_corners(std::vector<float>& eig, int w, int h, int max_corners, double quality, double min_distance,
+                          const float* seeds, int n_seed, float* corners_xy, float* scores, int cap);
+
 extern "C" int ora_good_features(const uint8_t* img, int w, int h, int step,
                                  int max_corners, double quality, double min_distance,
                                  const float* seeds, int n_seed,
                                  float* corners_xy, float* scores, int cap) {
     std::vector<float> eig((size_t)w * h);
     ora_min_eigen_map(img, w, h, step, eig.data());
+    return select_corners(eig, w, h, max_corners, quality, min_distance, seeds, n_seed, corners_xy, scores, cap);
+}
+
+/* the same call on the row-streaming eigenvalue map (ora_opt.cpp): identical results, less memory traffic */
+extern "C" int ora_good_features_opt(const uint8_t* img, int w, int h, int step,
+                                     int max_corners, double quality, double min_distance,
+                                     const float* seeds, int n_seed,
+                                     float* corners_xy, float* scores, int cap) {
+    std::vector<float> eig((size_t)w * h);
+    ora_min_eigen_map_opt(img, w, h, step, eig.data());
+    return select_corners(eig, w, h, max_corners, quality, min_distance, seeds, n_seed, corners_xy, scores, cap);
+}
+
+static int select_corners(std::vector<float>& eig, int w, int h, int max_corners, double quality, double min_distance,
+                          const float* seeds, int n_seed, float* corners_xy, float* scores, int cap) {
     float max_val = eig[0];
     for (size_t i = 1; i < eig.size(); i++) max_val = std::max(max_val, eig[i]);
     /* threshold(eig, eig, maxVal*quality, 0, THRESH_TOZERO): double product, compared as float */

@@ -27,7 +27,10 @@ def lib(fast=False):
     if fast not in _LIBS:
         name = "libvfe_oracle_fast.so" if fast else "libvfe_oracle.so"
         path = os.path.join(_HERE, name)
-        if not os.path.exists(path):
+        override = os.environ.get("VFE_ORACLE_LIB")  # e.g. the sanitizer build (make -C oracle asan-test)
+        if override and not fast:
+            path = override
+        elif not os.path.exists(path):
             build(fast)
         _LIBS[fast] = C.CDLL(path)
     return _LIBS[fast]
@@ -119,15 +122,16 @@ def gauss7_kernel():
     return k
 
 
-def min_eigen_map(img):
+def min_eigen_map(img, opt=False):
     img, p = _u8(img)
     h, w = img.shape
     out = np.empty((h, w), np.float32)
-    lib().ora_min_eigen_map(p, w, h, w, _p(out, C.c_float))
+    (lib().ora_min_eigen_map_opt if opt else lib().ora_min_eigen_map)(p, w, h, w, _p(out, C.c_float))
     return out
 
 
-def good_features(img, max_corners, quality, min_distance, seeds=None, fast=False):
+def good_features(img, max_corners, quality, min_distance, seeds=None, fast=False, opt=False):
+    """opt: the row-streaming organisation of the same arithmetic (ora_opt.cpp), bit-identical results."""
     img, p = _u8(img)
     h, w = img.shape
     cap = max_corners if max_corners > 0 else w * h
@@ -139,17 +143,18 @@ def good_features(img, max_corners, quality, min_distance, seeds=None, fast=Fals
     else:
         sp, ns = None, 0
     L = lib(fast)
-    L.ora_good_features.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
-                                    C.c_double, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
-                                    C.POINTER(C.c_float), C.c_int]
-    n = L.ora_good_features(p, w, h, w, max_corners, quality, min_distance, sp, ns,
-                            _p(xy, C.c_float), _p(sc, C.c_float), cap)
+    fn = L.ora_good_features_opt if opt else L.ora_good_features
+    fn.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                   C.c_double, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
+                   C.POINTER(C.c_float), C.c_int]
+    n = fn(p, w, h, w, max_corners, quality, min_distance, sp, ns, _p(xy, C.c_float), _p(sc, C.c_float), cap)
     assert n >= 0
     return xy[:n].copy(), sc[:n].copy()
 
 
 def klt_track(prev, nxt, pts, win=21, max_level=3, max_iter=30, eps=0.01, min_eig_thr=1e-4,
-              init=None, fast=False, want_err=True):
+              init=None, fast=False, want_err=True, opt=False):
+    """opt: one derivative image per level and border-extended images (ora_opt.cpp), bit-identical results."""
     prev, pp = _u8(prev)
     nxt, pn = _u8(nxt)
     h, w = prev.shape
@@ -159,10 +164,11 @@ def klt_track(prev, nxt, pts, win=21, max_level=3, max_iter=30, eps=0.01, min_ei
     st = np.zeros(n, np.uint8)
     err = np.zeros(n, np.float32)
     L = lib(fast)
-    L.ora_klt_track.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int,
-                                C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint8),
-                                C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
-    L.ora_klt_track(pp, pn, w, h, w, _p(pts, C.c_float), n, _p(out, C.c_float), _p(st, C.c_uint8),
+    fn = L.ora_klt_track_opt if opt else L.ora_klt_track
+    fn.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int,
+                   C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint8),
+                   C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+    fn(pp, pn, w, h, w, _p(pts, C.c_float), n, _p(out, C.c_float), _p(st, C.c_uint8),
                     _p(err, C.c_float) if want_err else None, win, max_level, max_iter, eps, min_eig_thr,
                     0 if init is None else 1)
     return out, st, err

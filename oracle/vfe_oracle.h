@@ -52,6 +52,19 @@ int ora_klt_track(const uint8_t* prev, const uint8_t* next, int w, int h, int st
                   int win, int max_level, int max_iter, double eps, double min_eig_thr,
                   int use_initial_flow);
 
+/* The same three functions with the work organised as an optimised CPU library organises it (one derivative image per
+ * pyramid level, border-extended images, row-streaming eigenvalue map; ora_opt.cpp): bit-identical outputs, several
+ * times faster.  They are what the benchmark's CPU baseline times as `port_fast`. */
+void ora_min_eigen_map_opt(const uint8_t* img, int w, int h, int step, float* eig);
+int ora_good_features_opt(const uint8_t* img, int w, int h, int step,
+                          int max_corners, double quality, double min_distance,
+                          const float* seeds, int n_seed,
+                          float* corners_xy, float* scores, int cap);
+int ora_klt_track_opt(const uint8_t* prev, const uint8_t* next, int w, int h, int step,
+                      const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err,
+                      int win, int max_level, int max_iter, double eps, double min_eig_thr,
+                      int use_initial_flow);
+
 /* cv::undistortPoints, radtan model, normalised output; cam4 = fx fy cx cy, d5 = k1 k2 p1 p2 k3 */
 void ora_undistort_points(const float* pts, float* out, long long n, const double* cam4, const double* d5);
 
