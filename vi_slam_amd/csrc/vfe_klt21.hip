@@ -106,9 +106,13 @@ __device__ static inline void fetch_patch(const DImg& im, const uint8_t* fp, int
         }
         return;
     }
+    /* this path is rare: its row numbers are formed here, behind a statement the optimiser cannot look through -- hoisted
+     * out of the level loop they would sit in registers (or in scratch) for the whole kernel */
+    int pr = P.pr;
+    asm volatile("" : "+v"(pr));
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        const int row = 4 * i + P.pr;
+        const int row = 4 * i + pr;
         v[i] = make_uint2(0u, 0u);
         if (P.on && (4 * i + 4 <= NROWS || row < NROWS)) {
             const int y = padded ? y0 + row : reflect101(y0 + row, im.h);
@@ -278,6 +282,7 @@ __device__ static inline int piece_residual(const unsigned* areaJ, const unsigne
 #ifndef KLT21_WPE
 #define KLT21_WPE 3
 #endif
+template <bool ONE_ITEM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, KLT21_WPE))) void k_klt21(KltParams p) {
     __shared__ __align__(16) unsigned s_patch[4][PATCH_DW];
     __shared__ __align__(16) unsigned s_patch2[4][PATCH_DW]; /* template patch for the residual pass */
@@ -306,7 +311,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
      * group of 8 frames keeps its order. */
     const unsigned per_frame = (unsigned)max(1, p.cap / 4);
     const unsigned grouped = n_items / (8u * per_frame) * (8u * per_frame);
-    for (unsigned wg = blockIdx.x; wg < n_items; wg += gridDim.x) {
+    /* ONE_ITEM: the grid has a workgroup per item (every launch below 2^20 items), so nothing is invariant across a loop
+     * and nothing is kept in registers -- or spilled -- for a next round */
+    for (unsigned wg = blockIdx.x; wg < n_items; wg += ONE_ITEM ? n_items : gridDim.x) {
         unsigned item = wg;
         if (wg < grouped) {
             const unsigned xcd = wg & 7u, slot = wg >> 3, grp = slot / per_frame, within = slot - grp * per_frame;
@@ -466,5 +473,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
 
 void klt21_launch(const KltParams& p, hipStream_t stream) {
     const unsigned items = (p.total_work + 3u) / 4u;
-    hipLaunchKernelGGL(k_klt21, dim3(items < (1u << 20) ? items : (1u << 20)), dim3(64), 0, stream, p);
+    if (items <= (1u << 20)) hipLaunchKernelGGL(k_klt21<true>, dim3(items), dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL(k_klt21<false>, dim3(1u << 20), dim3(64), 0, stream, p);
 }

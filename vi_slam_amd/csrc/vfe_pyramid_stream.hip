@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
 
         auto store_row = [&](int oy, u32 o0, u32 o1, u32 rv0, u32 rv1) {
             uint8_t* drow = dp + (ptrdiff_t)oy * dst.pitch + X0;
-            if (full_lane) *reinterpret_cast<uint2*>(drow) = make_uint2(o0, o1);
+            if (full_lane) *reinterpret_cast<uint2*>(drow) = make_uint2(o0, o1); /* plain stores: the next level reads them back from cache (non-temporal ones cost 15 % of the three launches) */
             else if (out_lane) {
                 const u32 oo[2] = {o0, o1};
                 for (int k = 0; k < 8 && X0 + k < DW; k++) drow[k] = (uint8_t)(oo[k >> 2] >> (8 * (k & 3)));
