@@ -44,7 +44,7 @@ $(LIBDIR)/libvfe.so: $(HIP_OBJS) | $(LIBDIR)
 
 # host side: SLAMEngine + framework adapters (C++17), linked against libvfe.so next to it
 $(LIBDIR)/libvi_slam_amd.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/libvfe.so
-	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$(HOST)/include -Iinclude -shared -o $@ $(HOST_SRCS) -L$(LIBDIR) -lvfe -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -lpthread
+	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$(HOST)/include -Iinclude -shared -o $@ $(HOST_SRCS) -L$(LIBDIR) -lvfe -L/opt/rocm/lib -lamdhip64 -ldl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -lpthread
 
 # the soak program also asks the HIP runtime how much device memory is in use
 tests/cpp/bin/test_soak: tests/cpp/test_soak.cpp tests/cpp/gpu_test_frames.hpp $(LIBDIR)/libvi_slam_amd.so

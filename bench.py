@@ -564,6 +564,24 @@ def run_reloc_leg(rk, steps, warmup, counters, force_collective=False):
            "collective": ("all_gather (RCCL)" if rk.world > 1 and not rk.gloo else "all_gather (gloo rehearsal)" if rk.world > 1
                           else "all_gather (RCCL, one-rank group, forced)" if force_collective else "none (one shard)"),
            "roofline": roof, "kernels": kernels}
+    if rk.world == 1:
+        # the same query set through the C++ host (vi_slam::ShardedMatcher: scan, RCCL all-gathers issued from C++ over a
+        # one-rank communicator, merge; queries in and results out over the link, one synchronisation per call)
+        try:
+            from vi_slam_amd import engine as eng
+            sm = eng.ShardedMatcher((rk.dev.index or 0,))
+            sm.set_map(td.cpu().numpy())
+            ms = []
+            for i in range(max(5, steps // 3)):
+                ci, cd, _ = sm.match(q, KNN_RATIO)
+                ms.append(sm.last_ms)
+            ok_cpp, _ = verify_planted(q, ci, cd)
+            out["cpp_sharded_matcher"] = {"ms_per_query_set": float(np.median(ms[1:])), "collective": sm.collective,
+                                          "planted_neighbours_verified": bool(ok_cpp),
+                                          "includes": "query upload, scan, all-gather, merge, ratio test, result download"}
+            sm.close()
+        except (RuntimeError, OSError) as e:  # RCCL not loadable from C++ on this box: report, do not fail the leg
+            out["cpp_sharded_matcher"] = {"error": str(e)}
     if "k_match" in kernels:
         # the search kernel alone (sample + main launch of a step), without all-gather and merges
         km = kernels["k_match"]

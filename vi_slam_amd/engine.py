@@ -61,6 +61,15 @@ def lib():
             ("vis_batch_wait", [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
             ("vis_batch_points", [C.c_void_p, C.c_int, C.c_void_p, C.c_int], C.c_int),
             ("vis_batch_reset", [C.c_void_p], C.c_int),
+            ("vis_matcher_open", [C.POINTER(C.c_int), C.c_int], C.c_void_p),
+            ("vis_matcher_close", [C.c_void_p], None),
+            ("vis_matcher_is_open", [C.c_void_p], C.c_int),
+            ("vis_matcher_world", [C.c_void_p], C.c_int),
+            ("vis_matcher_error", [C.c_void_p], C.c_char_p),
+            ("vis_matcher_collective", [C.c_void_p], C.c_char_p),
+            ("vis_matcher_set_map", [C.c_void_p, C.c_void_p, C.c_longlong], C.c_int),
+            ("vis_matcher_match", [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p], C.c_int),
+            ("vis_matcher_last_ms", [C.c_void_p], C.c_double),
         ]:
             fn = getattr(L, name)
             fn.argtypes = args
@@ -275,3 +284,54 @@ class BatchFrontEnd:
 
     def reset(self):
         return bool(lib().vis_batch_reset(self._h))
+
+
+class ShardedMatcher:
+    """vi_slam::ShardedMatcher (C++): the map split over `devices` in contiguous row blocks, per-shard top-2 exchanged by
+    RCCL all-gathers issued from C++, merged on every device."""
+
+    def __init__(self, devices=()):
+        dev = (C.c_int * max(1, len(devices)))(*devices)
+        self._h = C.c_void_p(lib().vis_matcher_open(dev, len(devices)))
+        if not lib().vis_matcher_is_open(self._h):
+            msg = lib().vis_matcher_error(self._h).decode()
+            self.close()
+            raise RuntimeError(f"ShardedMatcher: {msg}")
+
+    def close(self):
+        if self._h:
+            lib().vis_matcher_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def world(self):
+        return lib().vis_matcher_world(self._h)
+
+    @property
+    def collective(self):
+        return lib().vis_matcher_collective(self._h).decode()
+
+    @property
+    def last_ms(self):
+        return lib().vis_matcher_last_ms(self._h)
+
+    def set_map(self, desc):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        if not lib().vis_matcher_set_map(self._h, desc.ctypes.data, len(desc)):
+            raise RuntimeError(lib().vis_matcher_error(self._h).decode())
+
+    def match(self, queries, ratio=0.7):
+        q = np.ascontiguousarray(queries, np.uint8)
+        nq = len(q)
+        idx = np.empty((nq, 2), np.int32)
+        dist = np.empty((nq, 2), np.int32)
+        good = np.empty(nq, np.uint8)
+        if not lib().vis_matcher_match(self._h, q.ctypes.data, nq, idx.ctypes.data, dist.ctypes.data, ratio, good.ctypes.data):
+            raise RuntimeError(lib().vis_matcher_error(self._h).decode())
+        return idx, dist, good.astype(bool)

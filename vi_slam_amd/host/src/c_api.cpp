@@ -1,6 +1,7 @@
 /* Flat C view of SLAMEngine for non-C++ harnesses (the Python streaming harness and tests). */
 #include "slam/slam_engine.hpp"
 #include "slam/batch_frontend.hpp"
+#include "slam/sharded_matcher.hpp"
 #include "slam/adapters/openvins_adapter.hpp"
 #include "slam/adapters/basalt_adapter.hpp"
 #include "slam/adapters/orbslam3_adapter.hpp"
@@ -211,5 +212,35 @@ int vis_batch_points(void* p, int stream, float* xy, int cap) {
     return n;
 }
 int vis_batch_reset(void* p) { return static_cast<BatchHandle*>(p)->fe.reset() ? 1 : 0; }
+
+/* ---- ShardedMatcher: map split over the devices, RCCL all-gather of the per-shard top-2 ------------------------------ */
+namespace {
+struct MatcherHandle { ShardedMatcher m; std::string err, coll; };
+}  // namespace
+
+void* vis_matcher_open(const int* devices, int ndev) {
+    MatcherHandle* h = new MatcherHandle;
+    std::vector<int> d(devices, devices + (ndev > 0 ? ndev : 0));
+    (void)h->m.open(d);
+    return h;
+}
+void vis_matcher_close(void* p) { delete static_cast<MatcherHandle*>(p); }
+int vis_matcher_is_open(void* p) { return static_cast<MatcherHandle*>(p)->m.isOpen() ? 1 : 0; }
+int vis_matcher_world(void* p) { return static_cast<MatcherHandle*>(p)->m.world(); }
+const char* vis_matcher_error(void* p) {
+    MatcherHandle* h = static_cast<MatcherHandle*>(p);
+    h->err = h->m.lastError();
+    return h->err.c_str();
+}
+const char* vis_matcher_collective(void* p) {
+    MatcherHandle* h = static_cast<MatcherHandle*>(p);
+    h->coll = h->m.collective();
+    return h->coll.c_str();
+}
+int vis_matcher_set_map(void* p, const uint8_t* desc, long long n) { return static_cast<MatcherHandle*>(p)->m.setMap(desc, n) ? 1 : 0; }
+int vis_matcher_match(void* p, const uint8_t* q, int nq, int* idx, int* dist, float ratio, uint8_t* good) {
+    return static_cast<MatcherHandle*>(p)->m.match(q, nq, idx, dist, ratio, good) ? 1 : 0;
+}
+double vis_matcher_last_ms(void* p) { return static_cast<MatcherHandle*>(p)->m.lastMatchMs(); }
 
 }  // extern "C"
