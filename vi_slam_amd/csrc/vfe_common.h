@@ -129,6 +129,24 @@ __host__ __device__ static inline int reflect101(int p, int n) {
 __device__ static inline uint32_t lane_up_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }   /* value of lane - 1 (wave_shr:1) */
 __device__ static inline uint32_t lane_down_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); } /* value of lane + 1 (wave_shl:1) */
 
+/* Workgroups are dealt round-robin over the 8 XCDs of the chip, each with its own L2.  A launch whose workgroups are
+ * numbered frame by frame (`per_frame` consecutive workgroups each) spreads every frame over all eight caches, and
+ * whatever its workgroups share -- halo rows and columns, cache lines straddled by neighbouring strips, overlapping
+ * keypoint windows -- is fetched from memory up to eight times.  This renumbering keeps frame f on XCD f % 8: workgroup
+ * `lin` works on (frame, within).  Any renumbering is correct as long as it is a bijection; the frames past the last
+ * whole group of eight keep their order. */
+__device__ static inline void xcd_frame_of(unsigned lin, unsigned per_frame, unsigned batch, unsigned& frame, unsigned& within) {
+    const unsigned grouped = (batch & ~7u) * per_frame;
+    if (lin < grouped) {
+        const unsigned xcd = lin & 7u, seq = lin >> 3, g = seq / per_frame;
+        within = seq - g * per_frame;
+        frame = g * 8u + xcd;
+    } else {
+        frame = lin / per_frame;
+        within = lin - frame * per_frame;
+    }
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 

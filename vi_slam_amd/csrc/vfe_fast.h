@@ -21,6 +21,7 @@ struct FastSet {
     int* counts[FAST_MAX_LEVELS];            /* [batch] */
     int cap[FAST_MAX_LEVELS];
     int band_h, strips_x[FAST_MAX_LEVELS], bands_y[FAST_MAX_LEVELS];
+    int batch;                               /* frames per image (set by the launcher) */
     unsigned item_begin[FAST_MAX_LEVELS + 1]; /* first (frame, band, strip) work item of an image */
     unsigned seg_begin[FAST_MAX_LEVELS + 1];  /* first (frame, row, strip) segment of an image */
 };

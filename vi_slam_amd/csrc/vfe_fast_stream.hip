@@ -126,8 +126,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const int strips_x = S.strips_x[lv], band_h = S.band_h;
         const int W = img.w, H = img.h;
         const unsigned per_frame = (unsigned)(strips_x * S.bands_y[lv]);
-        const unsigned item = work - S.item_begin[lv];
-        const int b = item / per_frame, t_item = item - (unsigned)b * per_frame;
+        /* all strips and bands of a frame's level on one XCD: neighbouring strips straddle cache lines, bands share their
+         * halo rows (a level's item count is a multiple of 8 whenever the batch is, so the global work number and the
+         * level's own agree about the XCD; other batch sizes keep the plain order) */
+        unsigned fb, t_item;
+        xcd_frame_of(work - S.item_begin[lv], per_frame, (S.batch & 7) ? 0u : (unsigned)S.batch, fb, t_item);
+        const int b = (int)fb;
         const int sxi = t_item % strips_x, byi = t_item / strips_x;
         const int X0 = sxi * FS_OUT + 4 * (lane - 1); /* image column of this lane's pixel 0 */
         const int y0 = byi * band_h;
@@ -377,6 +381,7 @@ static int fast_set_geometry(FastSet& S, int batch) {
     }
     if ((band_h + 8) % FQ_PERIOD != 0) { vfe_set_error("FAST: band height %d is not a whole number of row-loop turns", band_h); return VFE_E_INVALID; }
     S.band_h = band_h;
+    S.batch = batch;
     unsigned long long items = 0, segs = 0;
     for (int l = 0; l < S.n; l++) {
         S.strips_x[l] = div_up(S.img[l].w, FS_OUT);

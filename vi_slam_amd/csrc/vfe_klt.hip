@@ -13,6 +13,7 @@
  * the detector.
  */
 #include "vfe_klt.h"
+#include <stdlib.h>
 #include <float.h>
 
 __device__ static inline long long wave_sum_i64(long long v) {
@@ -314,7 +315,8 @@ int klt_track_ordered(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, 
     ProfScope prof(VFE_K_KLT, (hipStream_t)stream);
     VFE_REQUIRE((long long)pts_cap * prev_levels[0].batch < (1ll << 31), "too many points");
     p.total_work = (unsigned)pts_cap * (unsigned)prev_levels[0].batch;
-    if (win == 21) {
+    static const unsigned generic_below = [] { const char* e = getenv("VFE_KLT_GENERIC_BELOW"); return e ? (unsigned)atoi(e) : 0u; }(); /* experiment switch */
+    if (win == 21 && p.total_work >= generic_below) {
         klt21_launch(p, (hipStream_t)stream);
     } else {
         hipLaunchKernelGGL(k_klt, dim3(p.total_work < 8192u ? p.total_work : 8192u), dim3(64), smem, (hipStream_t)stream, p);

@@ -158,8 +158,8 @@ __device__ static inline void mm_scan(const u32* __restrict__ query, int nq, int
     const float big = 1e30f; /* med3(a, b, big) = max(a, b) for keys; a maximum proper would first quiet each input */
     /* Three LDS tiles.  At the top of step s: Af holds tile s, tile s + 1 is complete in LDS, the packed rows of the
      * tiles from s + 2 on are on their way from memory, and the products of (tile s, query tile 0) are in flight.  The step
-     * writes tile s + 2, requests a tile further on and meets the other waves once, before it reads tile s + 1 for the
-     * first product of the next step.  The products of the next query tile are always issued before the keys of the
+     * writes tile s + 2, requests a tile further on, reads tile s + 1 for the first product of the next step as soon as
+     * its own products are issued, and meets the other waves once, at its end.  The products of the next query tile are always issued before the keys of the
      * current one are looked at, so that a tile's vector work runs in the shadow of the next tile's matrix work. */
     u32 pre[MM_AHEAD]; /* packed rows of tiles step + 2 .. step + 1 + MM_AHEAD */
     {
@@ -185,13 +185,13 @@ __device__ static inline void mm_scan(const u32* __restrict__ query, int nq, int
         for (int j = 0; j < QT; j++) {
             v16f nxt = acc;
             if (j + 1 < QT) nxt = tile(j + 1);
-            else {
-                __syncthreads();
-                if (more) {
-                    read_tile(rbuf, Af); /* this step's products have all been issued */
-                    set_cin(step + 1);
-                    nxt = tile(0);
-                }
+            else if (more) {
+                /* tile step + 1 has been complete since the barrier that ended the previous step: its first products are
+                 * issued before this step's barrier, which then passes in the shadow of the matrix pipe instead of
+                 * leaving it idle for the barrier and the LDS round trip */
+                read_tile(rbuf, Af); /* this step's products have all been issued */
+                set_cin(step + 1);
+                nxt = tile(0);
             }
             /* keeps the order: without it the compiler moves the matrix instructions down to where their results are
              * read, behind this tile's vector work */
@@ -210,6 +210,7 @@ __device__ static inline void mm_scan(const u32* __restrict__ query, int nq, int
             }
             acc = nxt;
         }
+        __syncthreads(); /* tile step + 2 is complete for the read that ends the next step; tile step + 1's buffer is free from there on */
         wbuf = wbuf == 2 ? 0 : wbuf + 1;
         rbuf = rbuf == 2 ? 0 : rbuf + 1;
     }

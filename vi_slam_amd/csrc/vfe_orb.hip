@@ -150,12 +150,16 @@ __global__ __launch_bounds__(256) void k_orb_resize(DImg src, DImg dst, const u3
 #define RS_BAND 16                      /* output rows per wave */
 #define RS_AHEAD 1                      /* source rows requested ahead (deeper: more registers, wasted rows at the end of a band, slower) */
 typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void k_orb_resize_rows(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab) {
+__global__ __launch_bounds__(256) void k_orb_resize_rows(DImg src, DImg dst, const u32* __restrict__ xtab, const u32* __restrict__ ytab, int gx, int gy) {
     __shared__ u32 s_rows[4][RS_SPAN_DW];
-    const int tid = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.z;
+    const int tid = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    /* all workgroups of a frame on one XCD: neighbouring segments and bands share source rows and cache lines */
+    unsigned fb, within;
+    xcd_frame_of(blockIdx.x, (unsigned)(gx * gy), (unsigned)dst.batch, fb, within);
+    const int b = (int)fb, by = (int)within / gx, bx = (int)within - by * gx;
     u32* s_row = s_rows[wv];
-    const int y0 = blockIdx.y * RS_BAND, y1 = min(y0 + RS_BAND, dst.h);
-    const int X0 = (blockIdx.x * 4 + wv) * RS_SEG; /* first output pixel of the wave */
+    const int y0 = by * RS_BAND, y1 = min(y0 + RS_BAND, dst.h);
+    const int X0 = (bx * 4 + wv) * RS_SEG; /* first output pixel of the wave */
     if (X0 >= dst.w) return;                       /* whole waves only: no workgroup barrier below */
     const int xe = min(X0 + RS_SEG, dst.w) - 1;
     const int s_lo = (int)(xtab[X0] >> 9) & ~3, s_hi = min((int)(xtab[xe] >> 9) + 1, src.w - 1);
@@ -325,13 +329,16 @@ __device__ static inline int row16_sum(int v) {
                            * (2 x quota of a level's thousands) then fill the four 16-lane rows of the response pass */
 #define HARRIS_CHUNKS 32  /* single-wave workgroups per (level, frame) */
 
-__global__ __launch_bounds__(64) void k_orb_harris(OrbLevels L) {
+__global__ __launch_bounds__(64) void k_orb_harris(OrbLevels L, int nlevels, int batch) {
     __shared__ u32 s_xy[HARRIS_KP], s_key[HARRIS_KP];
     __shared__ u32 s_win[4][28];
-    const int l = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    /* a frame's workgroups (all chunks of all levels) on one XCD: the 9 x 9 windows of neighbouring candidates overlap */
+    unsigned fb, within;
+    xcd_frame_of(blockIdx.x, (unsigned)(HARRIS_CHUNKS * nlevels), (unsigned)batch, fb, within);
+    const int b = (int)fb, l = (int)within / HARRIS_CHUNKS, chunk = (int)within - l * HARRIS_CHUNKS, lane = threadIdx.x;
     const int cap = L.cap[l];
     const int n = min(L.cnt[l][b], cap);
-    if ((int)(blockIdx.x * HARRIS_KP) >= n) return;
+    if (chunk * HARRIS_KP >= n) return;
     const int* kps = L.kps[l] + (size_t)b * cap * 3;
     u32* key = L.key[l] + (size_t)b * cap;
     u32* skey = L.skey[l] + (size_t)b * cap;
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(64) void k_orb_harris(OrbLevels L) {
      * 7x7 block */
     const int row = lane >> 4, sub = lane & 15;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int i0 = blockIdx.x * HARRIS_KP; i0 < n; i0 += HARRIS_CHUNKS * HARRIS_KP) { /* wave-uniform */
+    for (int i0 = chunk * HARRIS_KP; i0 < n; i0 += HARRIS_CHUNKS * HARRIS_KP) { /* wave-uniform */
         const int i = i0 + lane;
         const bool mine = lane < HARRIS_KP && i < n;
         int kx = 0, ky = 0;
@@ -603,13 +610,18 @@ __global__ __launch_bounds__(256) void k_orb_desc(OrbLevels L, vfe_orb_kp* __res
     __shared__ __align__(16) unsigned short s_h[4][DP_ROWS][DP_W]; /* horizontal blur sums of the keypoint's window */
     __shared__ __align__(16) u32 s_raw[4][DP_ROWS][DP_W / 4];       /* the window itself */
     const int lane = threadIdx.x & 63;
-    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), nwaves = (gridDim.x * 256u) >> 6;
-    const unsigned total = (unsigned)batch * (unsigned)out_cap;
+    const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    /* items are workgroups (four consecutive keypoints of a frame), a frame's items all on one XCD: keypoints come in
+     * (octave, y, x) order and the 43 x 48 windows of neighbours overlap; the grid is a multiple of 8, so a workgroup
+     * stays on its XCD from item to item */
+    const unsigned per_frame = ((unsigned)out_cap + 3u) / 4u, total = (unsigned)batch * per_frame;
     unsigned short* hs = s_h[threadIdx.x >> 6][0];
     u32* raw = s_raw[threadIdx.x >> 6][0];
-    for (unsigned w = wave; w < total; w += nwaves) {
-        const int b = w / (unsigned)out_cap, i = w - (unsigned)b * (unsigned)out_cap;
-        if (i >= counts[b]) continue;
+    for (unsigned item = blockIdx.x; item < total; item += gridDim.x) {
+        unsigned fb, within;
+        xcd_frame_of(item, per_frame, (unsigned)batch, fb, within);
+        const int b = (int)fb, i = (int)(within * 4u + wv);
+        if (i >= out_cap || i >= counts[b]) continue;
         vfe_orb_kp* kp = kps + (size_t)b * out_cap + i;
         const int l = kp->octave, px = kp->lx, py = kp->ly;
         const DImg& I = L.raw[l];
@@ -822,9 +834,10 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
             const DImg& sl = L.raw[l - 1];
             const bool rows_ok = (((uintptr_t)sl.data | (uintptr_t)sl.pitch | (uintptr_t)sl.fstride) & 3) == 0 && sl.sub_n == 1 &&
                                  W.w[l - 1] <= 2 * W.w[l] && W.h[l] <= 65535 && batch <= 65535;
-            if (rows_ok)
-                hipLaunchKernelGGL(k_orb_resize_rows, dim3(div_up(W.w[l], 4 * RS_SEG), div_up(W.h[l], RS_BAND), batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab);
-            else
+            if (rows_ok) {
+                const int gx = div_up(W.w[l], 4 * RS_SEG), gy = div_up(W.h[l], RS_BAND);
+                hipLaunchKernelGGL(k_orb_resize_rows, dim3((unsigned)gx * gy * batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab, gx, gy);
+            } else
                 hipLaunchKernelGGL(k_orb_resize, dim3((per_frame + 255) / 256, batch), dim3(256), 0, st, sl, L.raw[l], xtab, ytab, wn, per_frame);
             VFE_LAUNCH_CHECK();
         }
@@ -848,7 +861,7 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
         VFE_HIP(hipMemsetAsync(ws + W.hist_off, 0, W.hist_bytes, st));
         hipLaunchKernelGGL(k_orb_hist, dim3(SEL_CHUNKS, nlevels, batch), dim3(256), 0, st, L);
         VFE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_orb_harris, dim3(HARRIS_CHUNKS, nlevels, batch), dim3(64), 0, st, L);
+        hipLaunchKernelGGL(k_orb_harris, dim3((unsigned)HARRIS_CHUNKS * nlevels * batch), dim3(64), 0, st, L, nlevels, batch);
         VFE_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_orb_thresh, dim3(nlevels, batch), dim3(1024), 0, st, L, lvl_count);
         VFE_LAUNCH_CHECK();
@@ -857,8 +870,7 @@ extern "C" int vfe_dev_orb_extract(const vfe_dimg* img, int nfeatures, float sca
     }
     {
         ProfScope prof(VFE_K_ORB_DESC, st);
-        const unsigned waves = (unsigned)batch * (unsigned)cap;
-        const unsigned blocks = (waves + 3) / 4;
+        const unsigned blocks = (unsigned)batch * (((unsigned)cap + 3u) / 4u);
         hipLaunchKernelGGL(k_orb_desc, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, L, kps, desc, counts, cap, batch);
         VFE_LAUNCH_CHECK();
     }
