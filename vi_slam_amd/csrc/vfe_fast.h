@@ -8,6 +8,7 @@
  * different sizes, all with the same number of frames, is processed by one launch of each kernel. */
 #define FS_OUT 248
 #define FS_ROWCAP 128
+#define FS_HEAD 4 /* a segment's first keypoints are staged in a compact array (most segments hold 0..3): see k_fast_scatter_stream */
 #define FAST_MAX_LEVELS 12
 struct FastImg {
     const uint8_t* data;
@@ -25,7 +26,7 @@ struct FastSet {
     unsigned item_begin[FAST_MAX_LEVELS + 1]; /* first (frame, band, strip) work item of an image */
     unsigned seg_begin[FAST_MAX_LEVELS + 1];  /* first (frame, row, strip) segment of an image */
 };
-struct FastSetWs { size_t rowcnt_off, rowoff_off, tmp_off, total; };
+struct FastSetWs { size_t rowcnt_off, rowoff_off, head_off, tmp_off, total; };
 FastImg fast_img(const DImg& d);
 FastSetWs fast_set_layout(int n, const int* w, const int* h, int batch);
 /* FAST on every image of the set (each at least 16x16); results as fast_detect's */

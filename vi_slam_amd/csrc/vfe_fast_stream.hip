@@ -111,7 +111,7 @@ __device__ static inline u32 fast_score_window(const u32 (&R)[7][3], int t) {
 
 /* One wave per workgroup: items differ in length with their share of candidates, and a workgroup's LDS is held until
  * its slowest wave ends. */
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_queue(FastSet S, int threshold, int border, uint8_t* __restrict__ rowcnt, u32* __restrict__ tmp) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_queue(FastSet S, int threshold, int border, uint8_t* __restrict__ rowcnt, u32* __restrict__ head, u32* __restrict__ tmp) {
     __shared__ u32 img_ring[FQ_IR][64];
     __shared__ u32 sc_ring[FQ_SR][64];
     __shared__ unsigned short queue[FQ_QCAP];
@@ -248,11 +248,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     pos = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, pos));
                     pos = __builtin_amdgcn_mbcnt_hi((u32)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m2, pos));
                     pos = __builtin_amdgcn_mbcnt_hi((u32)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m3, pos));
-                    u32* dst = tmp + (seg0 + (size_t)M * strips_x) * FS_ROWCAP;
+                    /* the first FS_HEAD keypoints of a segment go to a compact array (16 bytes per segment), the rest to the
+                     * segment's full-size slot: with one keypoint per segment on average, a 512-byte slot per segment
+                     * made the scatter pass fetch a cache line per keypoint */
+                    const size_t sg = seg0 + (size_t)M * strips_x;
+                    u32* dst_h = head + sg * FS_HEAD;
+                    u32* dst = tmp + sg * FS_ROWCAP;
                     const u32 sc[4] = {SP[SCN][0] & 0xFFFFu, SP[SCN][0] >> 16, SP[SCN][1] & 0xFFFFu, SP[SCN][1] >> 16};
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        if (kp[k]) { dst[pos] = (u32)(4 * (lane - 1) + k) | (sc[k] << 8); pos++; }
+                        if (kp[k]) { (pos < FS_HEAD ? dst_h : dst)[pos] = (u32)(4 * (lane - 1) + k) | (sc[k] << 8); pos++; }
                 }
             }
             if (lane == 0) rowcnt[seg0 + (size_t)M * strips_x] = (uint8_t)total;
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 /* one thread per (frame, row, strip) segment copies the segment's keypoints to their final offset */
 __global__ __launch_bounds__(256) void k_fast_scatter_stream(FastSet S, const uint8_t* __restrict__ rowcnt, const u32* __restrict__ rowoff,
-                                                             const u32* __restrict__ tmp) {
+                                                             const u32* __restrict__ head, const u32* __restrict__ tmp) {
     const unsigned seg = blockIdx.x * 256u + threadIdx.x;
     if (seg >= S.seg_begin[S.n]) return;
     const int n = rowcnt[seg];
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256) void k_fast_scatter_stream(FastSet S, const ui
     const u32 off0 = rowoff[seg];
     int* kps = S.kps[lv];
     for (int j = 0; j < n; j++) {
-        const u32 e = tmp[(size_t)seg * FS_ROWCAP + j];
+        const u32 e = j < FS_HEAD ? head[(size_t)seg * FS_HEAD + j] : tmp[(size_t)seg * FS_ROWCAP + j];
         const u32 off = off0 + j;
         if (off < (u32)cap) {
             int* o = kps + ((size_t)b * cap + off) * 3;
@@ -402,6 +407,7 @@ FastSetWs fast_set_layout(int n, const int* w, const int* h, int batch) {
     size_t o = 0;
     L.rowcnt_off = o; o += align_up(segs, 256);
     L.rowoff_off = o; o += align_up(segs * sizeof(u32), 256);
+    L.head_off = o; o += align_up(segs * FS_HEAD * sizeof(u32), 256);
     L.tmp_off = o; o += align_up(segs * FS_ROWCAP * sizeof(u32), 256);
     L.total = o;
     return L;
@@ -420,12 +426,13 @@ int fast_detect_set(FastSet& S, int batch, int threshold, int border, char* ws, 
     uint8_t* rowcnt = (uint8_t*)(ws + L.rowcnt_off);
     u32* rowoff = (u32*)(ws + L.rowoff_off);
     u32* tmp = (u32*)(ws + L.tmp_off);
+    u32* head = (u32*)(ws + L.head_off);
     const unsigned total = S.item_begin[S.n], n_seg = S.seg_begin[S.n];
-    hipLaunchKernelGGL(k_fast_queue, dim3(total < (1u << 22) ? total : (1u << 22)), dim3(64), 0, st, S, threshold, border, rowcnt, tmp);
+    hipLaunchKernelGGL(k_fast_queue, dim3(total < (1u << 22) ? total : (1u << 22)), dim3(64), 0, st, S, threshold, border, rowcnt, head, tmp);
     VFE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_fast_scan_stream, dim3(batch, S.n), dim3(1024), 0, st, S, rowcnt, rowoff);
     VFE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_fast_scatter_stream, dim3((n_seg + 255) / 256), dim3(256), 0, st, S, rowcnt, rowoff, tmp);
+    hipLaunchKernelGGL(k_fast_scatter_stream, dim3((n_seg + 255) / 256), dim3(256), 0, st, S, rowcnt, rowoff, head, tmp);
     VFE_LAUNCH_CHECK();
     return VFE_OK;
 }
