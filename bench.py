@@ -751,8 +751,10 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8/int32/f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: 1920x1080 streams, 1000 Shi-Tomasi corners + 4-level KLT (win 21) + refill, "
-                               f"{B} independent streams per GPU per step, {args.loss:.0%} of the tracks dropped per step",
+        "config": {"workload": "the per-frame work of configs[1] (1920x1080, 1000 Shi-Tomasi corners + 4-level KLT, win 21, + "
+                               f"refill) batched as configs[3] batches it, over {B} independent streams per GPU per step "
+                               f"({args.loss:.0%} of the tracks dropped per step); configs[3]'s own 64 streams: see streams64, "
+                               "one live stream (configs[1] as stated): see single_stream",
                    "streams_per_gpu": B, "distinct_sequences": n_distinct, "track_loss_per_step": args.loss, "overlap": args.overlap,
                    "frame_bytes": W * H, "algo_bytes_per_frame": BYTES_FRAME,
                    "parallelism": f"streams sharded over {world} GPU(s), no collective"},

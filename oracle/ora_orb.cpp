@@ -184,3 +184,7 @@ extern "C" int ora_orb_extract(const uint8_t* img, int w, int h, int step,
     }
     return total;
 }
+
+/* the deterministic sine / cosine behind the steered pattern, exported so that tests can compare it with the C library's
+ * cosf / sinf (what cv::ORB calls) */
+extern "C" void ora_sincos_det(float x, float* s, float* c) { ora::sincos_det(x, s, c); }

@@ -65,6 +65,8 @@ int ora_klt_track_opt(const uint8_t* prev, const uint8_t* next, int w, int h, in
                       int win, int max_level, int max_iter, double eps, double min_eig_thr,
                       int use_initial_flow);
 
+void ora_sincos_det(float x, float* s, float* c);
+
 /* cv::undistortPoints, radtan model, normalised output; cam4 = fx fy cx cy, d5 = k1 k2 p1 p2 k3 */
 void ora_undistort_points(const float* pts, float* out, long long n, const double* cam4, const double* d5);
 
