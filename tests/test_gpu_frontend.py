@@ -91,6 +91,36 @@ def test_pyramid_two_levels_per_launch(cuda, w, h, levels):
                 assert np.array_equal(full[i].cpu().numpy(), np.pad(ref[l], B, mode="reflect")), f"border of level {l} frame {i}"
 
 
+@pytest.mark.parametrize("w,h,levels,frames", [(1920, 1080, 4, 48), (1280, 720, 5, 48), (752, 480, 4, 96), (640, 480, 4, 97),
+                                               (512, 272, 4, 100), (1008, 1096, 4, 50), (2000, 1208, 4, 34)])
+def test_pyramid_three_levels_per_launch(cuda, w, h, levels, frames, monkeypatch):
+    """Launches of many frames whose width is a multiple of 16 and height a multiple of 8 form levels 1 to 3 in one pass
+    over level 0 (bands of rows per wavefront, seams between bands and the image's top and bottom formed from rows kept in
+    LDS): every level and its reflect-101 border equal the oracle's pyrDown chain, for every frame of the launch, at
+    band splits of every kind (equal bands, a shorter last band, the smallest level 3 the path takes)."""
+    monkeypatch.setenv("VFE_PYR3_MIN_BLOCKS", "1")  # the library takes this path from a few hundred strips on
+    ims = [synth.noise(21, w, h), synth.scene(synth.BASE_SEED + 5, w, h, 2), synth.noise(22, w, h)]
+    ims[2][: h // 2] = 255  # saturated half: rounding at the top of the range
+    lv = capi.build_pyramid(capi.alloc_pyramid(to_dev([ims[i % 3] for i in range(frames)], cuda), levels))
+    B = capi.LK_BORDER
+    refs = []
+    for im in ims:
+        ref = [im]
+        for _ in range(1, levels):
+            ref.append(ora.pyr_down(ref[-1]))
+        refs.append(ref)
+    for l in range(1, levels):
+        t = lv[l]
+        b, lh, lw = t.shape
+        full = t.as_strided((b, lh + 2 * B, lw + 2 * B), t.stride(), t.storage_offset() - B * t.stride(1) - B).cpu().numpy()
+        for i in range(frames):
+            want = np.pad(refs[i % 3][l], B, mode="reflect")
+            if not np.array_equal(full[i], want):
+                bad = np.argwhere(full[i] != want)
+                raise AssertionError(f"level {l} frame {i}: {len(bad)} bytes differ, first at (row, col) {bad[0] - B}, "
+                                     f"rows {sorted(set(bad[:, 0] - B))[:12]}")
+
+
 @pytest.mark.parametrize("padded", [True, False])
 def test_klt_border_points_padded_and_unpadded(cuda, padded):
     """Points whose windows overhang every side of the image, at every level: identical results with

@@ -1,47 +1,97 @@
 #!/usr/bin/env python3
-"""Experiment: what would grouping the four points of a wave by iteration count be worth?  The largest iteration count
-a point needs at any level is found by raising the cap until its result stops changing; the tracker is then timed
-with the points in tile order, sorted by that count, and sorted by count within coarse tiles."""
-import os, sys, time
-import numpy as np
+"""Experiment: what grouping the tracker's points by their iteration counts could be worth.
+  mode collect : track the benchmark's 64 x 1000 points once with VFE_KLT_DEBUG_ITERS=1 and save every point's total
+                 iteration count (gpurun_out/klt_iters.npy)
+  mode time    : time vfe_dev_klt_track_ws (no err output) with the library's own order, and -- run with
+                 VFE_KLT_ORDER_GIVEN=1 -- with orders built here from the saved counts
+Usage: python tools/exp_klt_group.py collect|time [streams]"""
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
-from vi_slam_amd import capi, synth
-from oracle import oracle as ora
+import bench
+from vi_slam_amd import capi
 
+mode = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dev = torch.device("cuda:0")
-B, W, H = 64, 1920, 1080
-seq = [synth.scene(synth.BASE_SEED, W, H, t) for t in range(2)]
-f0 = capi.alloc_image(B, H, W, dev); f1 = capi.alloc_image(B, H, W, dev)
-f0.copy_(torch.from_numpy(np.broadcast_to(seq[0], (B, H, W)).copy()).to(dev))
-f1.copy_(torch.from_numpy(np.broadcast_to(seq[1], (B, H, W)).copy()).to(dev))
-p0 = capi.build_pyramid(capi.alloc_pyramid(f0, 4)); p1 = capi.build_pyramid(capi.alloc_pyramid(f1, 4))
-c, _ = ora.good_features(seq[0], 1000, 0.01, 20)
-c = c[np.lexsort((c[:, 0], c[:, 1] // 64))].astype(np.float32)
+host = bench.make_frames(0, B, min(16, B), 3)
+frames = []
+for t in range(3):
+    d = capi.alloc_image(B, bench.H, bench.W, dev)
+    d.copy_(torch.from_numpy(host[t]).to(dev))
+    frames.append(d)
+# a steady state: two steps of the front-end, then the tracker alone on frames 1 -> 2 with the points the step holds
+L = bench.FrontendLeg(frames, B, 0.05, dev)
+L.step()
+L.step()
+torch.cuda.synchronize()
+prev, nxt = L.pyr[L.cur ^ 1], L.pyr[L.cur]
+pts, n = L.fe.pts.clone(), L.fe.n_pts.clone()
+out = torch.zeros_like(pts)
+st = torch.zeros(pts.shape[:2], dtype=torch.uint8, device=dev)
+err = torch.zeros(pts.shape[:2], dtype=torch.float32, device=dev)
+ws = torch.zeros(capi.lib().vfe_klt_track_workspace(pts.shape[1], B), dtype=torch.uint8, device=dev)
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "klt_iters.npy")
 
-def track(pts, it=30):
-    d = torch.from_numpy(np.broadcast_to(pts, (B,) + pts.shape).copy()).to(dev)
-    out, st, _ = capi.klt_track(p0, p1, d, max_iter=it)
-    return out[0].cpu().numpy(), st[0].cpu().numpy()
 
-ref, _ = track(c)
-need = np.full(len(c), 30)
-for it in range(12, 0, -1):
-    o, _ = track(c, it)
-    same = (o.view(np.uint32) == ref.view(np.uint32)).all(axis=1)
-    need[same] = it
-print("iteration cap needed per point: histogram", np.bincount(need)[:14], "mean %.2f" % need.mean())
-g = need[: len(c) // 4 * 4].reshape(-1, 4)
-print("tile order: mean of wave maxima %.2f" % g.max(axis=1).mean())
-
-def run(pts, tag):
-    d = torch.from_numpy(np.broadcast_to(pts, (B,) + pts.shape).copy()).to(dev)
-    capi.klt_track(p0, p1, d); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5): capi.klt_track(p0, p1, d)
+def timeit(label, reps=20):
+    capi.klt_track_ws(prev, nxt, pts, n, out, st, None, win=bench.WIN, workspace=ws)
     torch.cuda.synchronize()
-    print(f"{tag:36s} {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms")
-run(c, "tile order")
-run(c[np.argsort(need, kind="stable")], "sorted by needed cap")
-tile = (c[:, 1] // 270).astype(int) * 8 + (c[:, 0] // 480).astype(int)
-run(c[np.lexsort((need, tile))], "by cap within 480x270 tiles")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        capi.klt_track_ws(prev, nxt, pts, n, out, st, None, win=bench.WIN, workspace=ws)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{label:46s} {e0.elapsed_time(e1) / reps:.4f} ms", flush=True)
+
+
+if mode == "collect":
+    capi.klt_track_ws(prev, nxt, pts, n, out, st, err, win=bench.WIN, workspace=ws)
+    torch.cuda.synchronize()
+    it = err.cpu().numpy()
+    np.save(path, it)
+    nn = n.cpu().numpy()
+    v = np.concatenate([it[b, :nn[b]] for b in range(B)])
+    print("iterations per point: mean %.2f  median %.0f  p90 %.0f  p99 %.0f  max %.0f" % (v.mean(), np.median(v), np.percentile(v, 90), np.percentile(v, 99), v.max()))
+    w4 = np.concatenate([it[b, :nn[b] // 4 * 4].reshape(-1, 4) for b in range(B)])
+    print("caller order, waves of four: mean of max %.2f (mean %.2f)" % (w4.max(axis=1).mean(), w4.mean()))
+else:
+    it = np.load(path)
+    nn = n.cpu().numpy()
+    cap = pts.shape[1]
+    given = os.environ.get("VFE_KLT_ORDER_GIVEN") == "1"
+    if not given:
+        timeit("library order (rim class, tile)")
+    else:
+        p = pts.cpu().numpy()
+        W, H = bench.W, bench.H
+
+        def rim_class(x, y):
+            rim = np.minimum(np.minimum(x, W - 1 - x), np.minimum(y, H - 1 - y))
+            cls = np.zeros(len(x), np.int64)
+            for c in range(4):
+                cls += (rim >= (11 << c)).astype(np.int64) * (cls == c)
+            return cls
+
+        def set_order(keyfn, label):
+            o = np.zeros((B, cap), np.uint16)
+            mx = []
+            for b in range(B):
+                k = nn[b]
+                x = np.clip(p[b, :k, 0].astype(np.int64), 0, W - 1); y = np.clip(p[b, :k, 1].astype(np.int64), 0, H - 1)
+                idx = keyfn(x, y, it[b, :k])
+                o[b, :k] = idx
+                g = it[b, idx][: k // 4 * 4].reshape(-1, 4)
+                mx.append(g.max(axis=1).mean())
+            ws.view(torch.int16)[: B * cap].copy_(torch.from_numpy(o.view(np.int16).reshape(-1)).to(dev))
+            timeit(f"{label} (mean of max {np.mean(mx):.2f})")
+
+        tile = lambda x, y: (y >> 6) * 31 + (x >> 6)
+        set_order(lambda x, y, i: np.lexsort((tile(x, y), rim_class(x, y))), "rim class, tile (numpy)")
+        set_order(lambda x, y, i: np.lexsort((tile(x, y), -i, rim_class(x, y))), "rim class, iterations desc, tile")
+        set_order(lambda x, y, i: np.lexsort((tile(x, y), -np.minimum(i // 4, 6), rim_class(x, y))), "rim class, iteration bucket /4 desc, tile")
+        set_order(lambda x, y, i: np.lexsort((-i, tile(x, y), rim_class(x, y))), "rim class, tile, iterations desc within tile")
+        set_order(lambda x, y, i: np.lexsort((tile(x, y), -i)), "iterations desc, tile")

@@ -8,6 +8,7 @@
  * cv::pyrDown.  Algorithmic traffic per output pixel: 4 source bytes + 1 written byte.
  */
 #include "vfe_common.h"
+#include <stdlib.h>
 
 #define PD_TW 128
 #define PD_TH 16
@@ -189,10 +190,29 @@ int pyr_fused2_launch(const DImg& s1, const DImg& d2, const DImg& d3, hipStream_
 #define PYR_FUSE_MAX_PIXELS (1 << 20)
 #define PYR_FUSE_MAX_TILES 4500
 
+/* vfe_pyramid_stream3.hip: three levels per launch, one workgroup per 496-column strip of a frame.  It needs enough
+ * frames in the launch to fill the chip with such workgroups. */
+bool pyr3_stream_ok(const DImg& s, const DImg& d1, const DImg& d2, const DImg& d3);
+int pyr3_stream_launch(const DImg& s, const DImg& d1, const DImg& d2, const DImg& d3, hipStream_t st);
+#define PYR3_MIN_BLOCKS 256
+static long long pyr3_min_blocks() { /* VFE_PYR3_MIN_BLOCKS: for tests and measurements, read at every call */
+    const char* e = getenv("VFE_PYR3_MIN_BLOCKS");
+    return e && *e ? atoll(e) : (long long)PYR3_MIN_BLOCKS;
+}
+
 extern "C" int vfe_dev_build_pyramid(const vfe_dimg* levels, int nlevels, void* stream) {
     VFE_REQUIRE(levels && nlevels >= 1 && nlevels <= VFE_MAX_LEVELS, "nlevels out of range");
     for (int l = 1; l < nlevels;) {
         int rc;
+        if (l + 2 < nlevels && !vfe_check_dimg(&levels[l - 1], "src") && !vfe_check_dimg(&levels[l], "dst") &&
+            !vfe_check_dimg(&levels[l + 1], "dst") && !vfe_check_dimg(&levels[l + 2], "dst") &&
+            (long long)((levels[l].width / 8 + 61) / 62) * levels[l - 1].batch >= pyr3_min_blocks() &&
+            pyr3_stream_ok(to_dimg(&levels[l - 1]), to_dimg(&levels[l]), to_dimg(&levels[l + 1]), to_dimg(&levels[l + 2]))) {
+            ProfScope prof(VFE_K_PYR_DOWN, (hipStream_t)stream);
+            if ((rc = pyr3_stream_launch(to_dimg(&levels[l - 1]), to_dimg(&levels[l]), to_dimg(&levels[l + 1]), to_dimg(&levels[l + 2]), (hipStream_t)stream))) return rc;
+            l += 3;
+            continue;
+        }
         /* two small levels in one launch where the source level carries a border (i.e. from level 1 on) */
         if (l + 1 < nlevels && (long long)levels[l - 1].width * levels[l - 1].height <= PYR_FUSE_MAX_PIXELS &&
             (long long)((levels[l + 1].width + 31) / 32) * ((levels[l + 1].height + 7) / 8) * levels[l + 1].batch <= PYR_FUSE_MAX_TILES &&
