@@ -13,7 +13,8 @@ from collections import defaultdict
 
 # slot -> (anchor kernel, all kernels of the slot)
 SLOTS = {
-    "k_pyr_down": ("k_pyr_down_stream", ["k_pyr_down_stream", "k_pyr_down", "k_pad_border"]),
+    # one scope = one k_pyr_down_stream (a level) or one k_pyr3_stream (levels 1 to 3)
+    "k_pyr_down": (("k_pyr_down_stream", "k_pyr3_stream"), ["k_pyr_down_stream", "k_pyr3_stream", "k_pyr_down", "k_pad_border"]),
     "k_gftt_eig": ("k_gftt_eig", ["k_gftt_eig"]),
     "k_gftt_select": ("k_gftt_select", ["k_gftt_select"]),
     "k_klt": ("k_klt21", ["k_klt21"]),
@@ -49,10 +50,12 @@ def slot_value(vals, slot, leg):
     if slot == "k_match":
         kernels = ["k_match_mm_batch"] if leg == "orb_match" else ["k_match_mm"]
         anchor = kernels[0]
-    if not vals.get(anchor):
+    anchors = anchor if isinstance(anchor, tuple) else (anchor,)
+    scopes = sum(len(vals.get(a, [])) for a in anchors)
+    if not scopes:
         return None, 0
     total = sum(sum(vals.get(k, [])) for k in kernels)
-    return total / len(vals[anchor]), len(vals[anchor])
+    return total / scopes, scopes
 
 
 def main():

@@ -70,6 +70,8 @@ struct ProfScope {
  * buffers as soon as it has the status code.  ForkGuard does that on scope exit unless the join has been made. */
 struct AuxStream { hipStream_t s; hipEvent_t fork, join; };
 AuxStream* vfe_aux_stream(hipStream_t caller);
+/* vfe_pyramid.hip: will vfe_dev_build_pyramid form levels 1 to 3 of this pyramid in one launch? */
+bool vfe_pyramid_three_levels_per_launch(const vfe_dimg* levels, int nlevels);
 bool vfe_overlap_on();
 struct ForkGuard {
     AuxStream* a; hipStream_t st; bool joined;

@@ -307,7 +307,7 @@ extern "C" int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const v
     hipStream_t st = (hipStream_t)stream;
     AuxStream* aux = vfe_overlap_on() ? vfe_aux_stream(st) : nullptr;
     ForkGuard guard{nullptr, st, false};
-    const EigBeside beside = eig_beside_policy(w, h, batch);
+    const EigBeside beside = eig_beside_policy(w, h, batch, vfe_pyramid_three_levels_per_launch(next_levels, nlevels));
     const bool fork_late = beside.after_pyramid;
     auto fork_eig = [&]() -> int {
         VFE_HIP(hipEventRecord(aux->fork, st));

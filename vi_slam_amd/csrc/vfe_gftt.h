@@ -34,13 +34,16 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
  * short pyramid launches in front of them) only start as its waves retire.  A long pass overlaps the whole tracker anyway;
  * a shorter one is better held to 3 or 2 workgroups per CU (requested as spare LDS per workgroup), and a short one is
  * better started behind the pyramid.  Measured on 1080p front-end steps, 8 to 256 streams (8640 strip rows per frame):
- * 256 streams uncapped, 128 three workgroups per CU (+3 %), 64 two (+7 %), 32 and fewer behind the pyramid (+4 .. +14 %). */
+ * 256 streams uncapped, 128 three workgroups per CU (+3 %), 64 two (+7 %), 32 and fewer behind the pyramid (+4 .. +14 %).
+ * Where the pyramid is one launch of eight-wave workgroups (`pyramid_one_launch`), an uncapped pass in front of it leaves
+ * no CU with room for such a workgroup until its own grid has been handed out: 256 streams 1.70 ms per step uncapped,
+ * 1.61 ms with three workgroups per CU (behind the pyramid: 1.66). */
 struct EigBeside { int wgs_per_cu; bool after_pyramid; };
 /* strip rows of a launch: the measure of its length (the number of waves is not -- the band height adapts to the batch) */
 static inline long long eig_strip_rows(int w, int h, int batch) { return (long long)div_up(w, EV_OUT) * h * batch; }
-static inline EigBeside eig_beside_policy(int w, int h, int batch) {
+static inline EigBeside eig_beside_policy(int w, int h, int batch, bool pyramid_one_launch) {
     const long long rows = eig_strip_rows(w, h, batch); /* 8640 per 1080p frame */
-    if (rows >= 1600000) return {0, false};
+    if (rows >= 1600000) return {pyramid_one_launch ? 3 : 0, false};
     if (rows >= 800000) return {3, false};
     if (rows >= 400000) return {2, false};
     return {0, true};

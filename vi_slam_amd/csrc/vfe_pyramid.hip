@@ -190,24 +190,32 @@ int pyr_fused2_launch(const DImg& s1, const DImg& d2, const DImg& d3, hipStream_
 #define PYR_FUSE_MAX_PIXELS (1 << 20)
 #define PYR_FUSE_MAX_TILES 4500
 
-/* vfe_pyramid_stream3.hip: three levels per launch, one workgroup per 496-column strip of a frame.  It needs enough
- * frames in the launch to fill the chip with such workgroups. */
+/* vfe_pyramid_stream3.hip: three levels per launch, one workgroup of up to eight waves per strip of a frame.  A lone
+ * workgroup needs ~55 us for a 1080-row strip whatever the launch holds, so the launch must bring enough strips to fill
+ * the chip.  Measured on 1080p (two strips per frame), this path against one launch per level: 16 frames 55 / 32 us,
+ * 32 frames 56 / 50, 64 frames 65 / 64, 128 frames 84 / 113, 256 frames 154 / 206-217. */
 bool pyr3_stream_ok(const DImg& s, const DImg& d1, const DImg& d2, const DImg& d3);
 int pyr3_stream_launch(const DImg& s, const DImg& d1, const DImg& d2, const DImg& d3, hipStream_t st);
-#define PYR3_MIN_BLOCKS 256
+#define PYR3_MIN_BLOCKS 160
 static long long pyr3_min_blocks() { /* VFE_PYR3_MIN_BLOCKS: for tests and measurements, read at every call */
     const char* e = getenv("VFE_PYR3_MIN_BLOCKS");
     return e && *e ? atoll(e) : (long long)PYR3_MIN_BLOCKS;
 }
 
+/* levels l, l+1, l+2 from level l-1 in one launch? */
+static bool pyr3_applies(const vfe_dimg* levels, int nlevels, int l) {
+    return l + 2 < nlevels && !vfe_check_dimg(&levels[l - 1], "src") && !vfe_check_dimg(&levels[l], "dst") &&
+           !vfe_check_dimg(&levels[l + 1], "dst") && !vfe_check_dimg(&levels[l + 2], "dst") &&
+           (long long)((levels[l].width / 8 + 61) / 62) * levels[l - 1].batch >= pyr3_min_blocks() &&
+           pyr3_stream_ok(to_dimg(&levels[l - 1]), to_dimg(&levels[l]), to_dimg(&levels[l + 1]), to_dimg(&levels[l + 2]));
+}
+bool vfe_pyramid_three_levels_per_launch(const vfe_dimg* levels, int nlevels) { return levels && pyr3_applies(levels, nlevels, 1); }
+
 extern "C" int vfe_dev_build_pyramid(const vfe_dimg* levels, int nlevels, void* stream) {
     VFE_REQUIRE(levels && nlevels >= 1 && nlevels <= VFE_MAX_LEVELS, "nlevels out of range");
     for (int l = 1; l < nlevels;) {
         int rc;
-        if (l + 2 < nlevels && !vfe_check_dimg(&levels[l - 1], "src") && !vfe_check_dimg(&levels[l], "dst") &&
-            !vfe_check_dimg(&levels[l + 1], "dst") && !vfe_check_dimg(&levels[l + 2], "dst") &&
-            (long long)((levels[l].width / 8 + 61) / 62) * levels[l - 1].batch >= pyr3_min_blocks() &&
-            pyr3_stream_ok(to_dimg(&levels[l - 1]), to_dimg(&levels[l]), to_dimg(&levels[l + 1]), to_dimg(&levels[l + 2]))) {
+        if (pyr3_applies(levels, nlevels, l)) {
             ProfScope prof(VFE_K_PYR_DOWN, (hipStream_t)stream);
             if ((rc = pyr3_stream_launch(to_dimg(&levels[l - 1]), to_dimg(&levels[l]), to_dimg(&levels[l + 1]), to_dimg(&levels[l + 2]), (hipStream_t)stream))) return rc;
             l += 3;
