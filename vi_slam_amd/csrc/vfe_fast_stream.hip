@@ -111,6 +111,8 @@ __device__ static inline u32 fast_score_window(const u32 (&R)[7][3], int t) {
 
 /* One wave per workgroup: items differ in length with their share of candidates, and a workgroup's LDS is held until
  * its slowest wave ends. */
+/* ALIGNED: every image of the set has dword-aligned rows (one load instruction per row, in straight-line code) */
+template <bool ALIGNED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_queue(FastSet S, int threshold, int border, uint8_t* __restrict__ rowcnt, u32* __restrict__ head, u32* __restrict__ tmp) {
     __shared__ u32 img_ring[FQ_IR][64];
     __shared__ u32 sc_ring[FQ_SR][64];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
         auto load_row = [&](int yy) -> u32 {
             const uint8_t* row = ip + (size_t)min(max(yy, 0), H - 1) * img.pitch;
-            if (img.aligned) return *reinterpret_cast<const uint32_t*>(row + X0c); /* wave-uniform */
+            if (ALIGNED || img.aligned) return *reinterpret_cast<const uint32_t*>(row + X0c); /* wave-uniform */
             return (u32)row[min(max(X0, 0), W - 1)] | ((u32)row[min(max(X0 + 1, 0), W - 1)] << 8) |
                    ((u32)row[min(max(X0 + 2, 0), W - 1)] << 16) | ((u32)row[min(max(X0 + 3, 0), W - 1)] << 24);
         };
@@ -269,8 +271,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             constexpr int PH = decltype(phc)::value, ST = decltype(stc)::value;
             const int yy = y0 - 4 + t;
             {
-                const u32 c = pre[PH];
+                /* The row moves from its prefetch register into the ring by an instruction of its own, and only then is the
+                 * load for nine rows on issued: into the same prefetch register.  (Left to the compiler the row stays
+                 * where it was loaded, the new load gets a fresh register, and at the end of every turn of the loop nine
+                 * copies put the prefetch registers back -- behind a wait for all nine loads in flight.) */
+                u32 c;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(pre[PH]));
+                __builtin_amdgcn_sched_barrier(0);
                 pre[PH] = load_row(yy + FQ_AHEAD); /* clamped: always a valid address */
+                __builtin_amdgcn_sched_barrier(0);
                 R[PH][1] = c;
                 R[PH][0] = lane_up_u(c);
                 R[PH][2] = lane_down_u(c);
@@ -428,7 +437,10 @@ int fast_detect_set(FastSet& S, int batch, int threshold, int border, char* ws, 
     u32* tmp = (u32*)(ws + L.tmp_off);
     u32* head = (u32*)(ws + L.head_off);
     const unsigned total = S.item_begin[S.n], n_seg = S.seg_begin[S.n];
-    hipLaunchKernelGGL(k_fast_queue, dim3(total < (1u << 22) ? total : (1u << 22)), dim3(64), 0, st, S, threshold, border, rowcnt, head, tmp);
+    bool all_aligned = true;
+    for (int l = 0; l < S.n; l++) all_aligned = all_aligned && S.img[l].aligned;
+    if (all_aligned) hipLaunchKernelGGL(k_fast_queue<true>, dim3(total < (1u << 22) ? total : (1u << 22)), dim3(64), 0, st, S, threshold, border, rowcnt, head, tmp);
+    else hipLaunchKernelGGL(k_fast_queue<false>, dim3(total < (1u << 22) ? total : (1u << 22)), dim3(64), 0, st, S, threshold, border, rowcnt, head, tmp);
     VFE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_fast_scan_stream, dim3(batch, S.n), dim3(1024), 0, st, S, rowcnt, rowoff);
     VFE_LAUNCH_CHECK();

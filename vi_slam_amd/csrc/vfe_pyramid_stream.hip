@@ -35,13 +35,16 @@ template <int N> using ic = std::integral_constant<int, N>;
  * `once`: the launch reads far more than the caches hold, so its loads carry the non-temporal hint
  * (a 4 : 1 read / write stream moves ~10 % more bytes per second that way; the stores stay plain,
  * the next level reads them back from cache). */
-template <bool W16>
-__device__ static inline uint4 pyr_load_row(const DImg& src, const uint8_t* sp, int iy, int IX0, bool once) {
+template <bool W16, bool once>
+__device__ static inline uint4 pyr_load_row(const DImg& src, const uint8_t* sp, int iy, int IX0) {
     const uint8_t* row = sp + (size_t)reflect101(iy, src.h) * src.pitch;
-    if (IX0 >= 0 && IX0 + 15 < src.w) {
-        if (!once) return *reinterpret_cast<const uint4*>(row + IX0);
+    /* W16: every lane loads unconditionally, lanes outside the image a chunk inside it (never used) -- a load under a
+     * lane condition merges with the zeros of the other branch, which is a copy again */
+    const int IXc = W16 ? min(max(IX0, 0), src.w - 16) : IX0;
+    if (W16 || (IX0 >= 0 && IX0 + 15 < src.w)) {
+        if (!once) return *reinterpret_cast<const uint4*>(row + IXc);
         typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(row + IX0));
+        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(row + IXc));
         return make_uint4(v.x, v.y, v.z, v.w);
     }
     uint32_t w[4] = {0, 0, 0, 0};
@@ -71,10 +74,13 @@ __device__ static inline void pyr_hsums(const uint4& c, u32 lw, u32 rb, u32 (&hp
     for (int i = 0; i < 4; i++) hp[i] = r[2 * i] | (r[2 * i + 1] << 16);
 }
 
-/* W16: the source width is a multiple of 16 (no lane straddles the right rim) */
-template <bool PAD, bool W16>
-__global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int strips_x, int band_h, int bands_y, unsigned total_work, int read_once) {
-    const bool once = read_once != 0;
+/* W16: the source width is a multiple of 16 (no lane straddles the right rim); ONCE: non-temporal loads.  Both are
+ * template parameters so that a row's load is ONE instruction in straight-line code: a load goes out after the row it
+ * replaces has been consumed and lands in that row's registers.  (Issued earlier it gets registers of its own, and the
+ * compiler copies them back at the end of every trip round the loop behind an `s_waitcnt vmcnt(0)` -- all six loads in
+ * flight waited for, once per six rows; a run-time choice between two load instructions defeats the wait counting too.) */
+template <bool PAD, bool W16, bool ONCE>
+__global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int strips_x, int band_h, int bands_y, unsigned total_work) {
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
     const unsigned per_frame = (unsigned)(strips_x * bands_y);
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
         const int iy0 = 2 * oy0 - 2, iy1 = 2 * oy1; /* source rows iy0 .. iy1 */
         uint4 pre[PS_AHEAD];
 #pragma unroll
-        for (int k = 0; k < PS_AHEAD; k++) pre[k] = (iy0 + k <= iy1) ? pyr_load_row<W16>(src, sp, iy0 + k, IX0, once) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < PS_AHEAD; k++) pre[k] = pyr_load_row<W16, ONCE>(src, sp, min(iy0 + k, iy1), IX0);
         u32 A[3][4]; /* accumulators of three consecutive output rows, two 16-bit sums per dword */
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -130,13 +136,15 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
             u32 hp[4];
             {   /* even row 2m */
                 const uint4 cur = pre[2 * ph];
-                if (2 * m + PS_AHEAD <= iy1) pre[2 * ph] = pyr_load_row<W16>(src, sp, 2 * m + PS_AHEAD, IX0, once);
                 u32 lw = (u32)__shfl_up((int)cur.w, 1), rb = (u32)__shfl_down((int)cur.x, 1) & 0xFFu;
                 /* at the image rim the halo bytes are reflections this lane already holds:
                  * bytes -2, -1 = bytes 2, 1; byte 16 = byte 14 */
                 if (fix_l) lw = __builtin_amdgcn_perm(cur.x, cur.x, 0x01020c0cu);
                 if (fix_r) rb = (cur.w >> 16) & 0xFFu;
                 pyr_hsums(cur, lw, rb, hp);
+                __builtin_amdgcn_sched_barrier(0);
+                pre[2 * ph] = pyr_load_row<W16, ONCE>(src, sp, min(2 * m + PS_AHEAD, iy1), IX0); /* rows past the band: the last one again, unused */
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) { A[P][k] += hp[k]; A[C][k] += 6u * hp[k]; A[N][k] = hp[k] + 0x00800080u; }
                 const int oy = m - 1;
@@ -154,11 +162,13 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(DImg src, DImg dst, int
             }
             {   /* odd row 2m+1 (not needed after the last output row; harmless then) */
                 const uint4 cur = pre[2 * ph + 1];
-                if (2 * m + 1 + PS_AHEAD <= iy1) pre[2 * ph + 1] = pyr_load_row<W16>(src, sp, 2 * m + 1 + PS_AHEAD, IX0, once);
                 u32 lw = (u32)__shfl_up((int)cur.w, 1), rb = (u32)__shfl_down((int)cur.x, 1) & 0xFFu;
                 if (fix_l) lw = __builtin_amdgcn_perm(cur.x, cur.x, 0x01020c0cu);
                 if (fix_r) rb = (cur.w >> 16) & 0xFFu;
                 pyr_hsums(cur, lw, rb, hp);
+                __builtin_amdgcn_sched_barrier(0);
+                pre[2 * ph + 1] = pyr_load_row<W16, ONCE>(src, sp, min(2 * m + 1 + PS_AHEAD, iy1), IX0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) { A[C][k] += 4u * hp[k]; A[N][k] += 4u * hp[k]; }
             }
@@ -183,7 +193,7 @@ static bool vec_ok(const DImg& d, int align) {
 }
 bool pyr_down_stream_ok(const DImg& s, const DImg& d) { return vec_ok(s, 16) && vec_ok(d, 8); }
 
-typedef void (*pyr_kernel_t)(DImg, DImg, int, int, int, unsigned, int);
+typedef void (*pyr_kernel_t)(DImg, DImg, int, int, int, unsigned);
 
 #define PS_ONCE_BYTES (64ll << 20) /* a source this large is gone from the caches before anything reads it again */
 
@@ -200,10 +210,15 @@ static int waves_per_simd(pyr_kernel_t kern) {
 int pyr_down_stream_launch(const DImg& s, const DImg& d, hipStream_t st, bool* padded) {
     const bool pad = d.border == PS_BORDER && d.w % 8 == 0 && d.w >= 48 && d.h >= PS_BORDER + 2;
     const bool w16 = s.w % 16 == 0;
-    const pyr_kernel_t kern = pad ? (w16 ? k_pyr_down_stream<true, true> : k_pyr_down_stream<true, false>)
-                                  : (w16 ? k_pyr_down_stream<false, true> : k_pyr_down_stream<false, false>);
-    static int occ[4] = {0, 0, 0, 0};
-    int& o = occ[(pad ? 2 : 0) + (w16 ? 1 : 0)];
+    const bool once = (long long)s.w * s.h * s.batch >= PS_ONCE_BYTES;
+    static const pyr_kernel_t kerns[8] = {k_pyr_down_stream<false, false, false>, k_pyr_down_stream<false, false, true>,
+                                          k_pyr_down_stream<false, true, false>,  k_pyr_down_stream<false, true, true>,
+                                          k_pyr_down_stream<true, false, false>,  k_pyr_down_stream<true, false, true>,
+                                          k_pyr_down_stream<true, true, false>,   k_pyr_down_stream<true, true, true>};
+    const int ki = (pad ? 4 : 0) + (w16 ? 2 : 0) + (once ? 1 : 0);
+    const pyr_kernel_t kern = kerns[ki];
+    static int occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int& o = occ[ki];
     if (o == 0) o = waves_per_simd(kern);
     /* Band height: every wave is an item (strip x band x frame) and all waves of a round run side by
      * side, so the launch takes ceil(items / resident waves) rounds of (2 band + 9) source rows (two
@@ -220,8 +235,7 @@ int pyr_down_stream_launch(const DImg& s, const DImg& d, hipStream_t st, bool* p
     const int bands_y = div_up(d.h, band_h);
     const unsigned total = (unsigned)(strips_x * bands_y * d.batch), nblk = (total + 3) / 4;
     const dim3 grid(nblk < (1u << 20) ? nblk : (1u << 20));
-    const int read_once = (long long)s.w * s.h * s.batch >= PS_ONCE_BYTES;
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, s, d, strips_x, band_h, bands_y, total, read_once);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, s, d, strips_x, band_h, bands_y, total);
     VFE_LAUNCH_CHECK();
     *padded = pad;
     return VFE_OK;
