@@ -19,7 +19,7 @@ HOST_SRCS = $(wildcard $(HOST)/src/*.cpp)
 HOST_HDRS = $(wildcard $(HOST)/include/*/*.hpp) $(wildcard $(HOST)/include/*/*/*.hpp) include/vfe.h
 CPP_TESTS = $(patsubst tests/cpp/%.cpp,tests/cpp/bin/%,$(wildcard tests/cpp/*.cpp)) tests/cpp/bin/pc_client_video_callback
 
-HIP_TESTS = $(patsubst tests/hip/%.hip,tests/cpp/bin/%,$(wildcard tests/hip/*.hip)) tests/cpp/bin/valu_ceiling tests/cpp/bin/hbm_stream
+HIP_TESTS = $(patsubst tests/hip/%.hip,tests/cpp/bin/%,$(wildcard tests/hip/*.hip)) tests/cpp/bin/valu_ceiling tests/cpp/bin/hbm_stream tests/cpp/bin/mfma_ceiling
 
 all: $(LIBDIR)/libvfe_synth.so $(LIBDIR)/libvfe.so $(LIBDIR)/libvi_slam_amd.so $(CPP_TESTS) $(HIP_TESTS) oracle
 
@@ -68,6 +68,11 @@ tests/cpp/bin/%: tests/hip/%.hip $(HIP_HDRS)
 
 # measurement tool: VALU issue ceiling per instruction class (tools/valu_ceiling.hip)
 tests/cpp/bin/valu_ceiling: tools/valu_ceiling.hip
+	@mkdir -p tests/cpp/bin
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
+
+# measurement tool: what the matrix pipe sustains on the matcher's instruction (tools/mfma_ceiling.hip)
+tests/cpp/bin/mfma_ceiling: tools/mfma_ceiling.hip
 	@mkdir -p tests/cpp/bin
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
 
