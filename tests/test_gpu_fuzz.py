@@ -259,3 +259,24 @@ def test_fuzz_fundamental_ransac(cuda, case):
         assert inl[b] == rc, f"{tag}: {inl[b]} vs {rc}"
         assert np.array_equal(got[b, :n[b]], rst), tag
         assert np.array_equal(F[b].view(np.uint64), rF.view(np.uint64)), tag
+
+
+@pytest.mark.parametrize("case", range(8 * SCALE))
+def test_fuzz_pyramid_three_levels_per_launch(cuda, case, monkeypatch):
+    """Random geometries the one-launch pyramid takes (width a multiple of 16, height of 8, level 3 at least 48 x 34), a few
+    frames each: levels 1 to 3 and their reflect-101 borders against the oracle's pyrDown chain -- every band split, strip
+    count and last-strip width the sizes produce."""
+    monkeypatch.setenv("VFE_PYR3_MIN_BLOCKS", "1")
+    rng = np.random.default_rng(7000 + case)
+    w, h = 16 * int(rng.integers(24, 150)), 8 * int(rng.integers(34, 160))
+    imgs = _images(rng, w, h, int(rng.integers(1, 4)))
+    lv = capi.build_pyramid(capi.alloc_pyramid(_dev(imgs, cuda), 4))
+    B = capi.LK_BORDER
+    for i, im in enumerate(imgs):
+        ref = im
+        for l in range(1, 4):
+            ref = ora.pyr_down(ref)
+            t = lv[l]
+            b, lh, lw = t.shape
+            full = t.as_strided((b, lh + 2 * B, lw + 2 * B), t.stride(), t.storage_offset() - B * t.stride(1) - B)
+            assert np.array_equal(full[i].cpu().numpy(), np.pad(ref, B, mode="reflect")), f"{w}x{h} level {l} frame {i}"
