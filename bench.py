@@ -222,16 +222,18 @@ class Ranks:
         return float(t.item())
 
 
-def timed(rk, fn, steps, warmup):
+def timed(rk, fn, steps, warmup, events=True):
     """`warmup` untimed + exactly `steps` timed calls of fn between barrier + synchronize pairs; -> (seconds, the
-    slowest rank's; per-kernel HIP-event times of this rank inside the timed region)."""
+    slowest rank's; per-kernel HIP-event times of this rank inside the timed region).  `events=False`: without the library's
+    HIP events around every kernel (two event records per launch cost a short step tens of microseconds) -- for regions
+    whose kernel table comes from a pass of its own."""
     import torch
     from vi_slam_amd import capi
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     rk.barrier()
-    capi.prof_enable(True)
+    capi.prof_enable(events)
     capi.prof_read(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -421,7 +423,8 @@ def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg, over
     from vi_slam_amd import capi
     L = FrontendLeg(frames, batch, loss, rk.dev)
     capi.set_overlap(overlap)
-    elapsed, prof = timed(rk, L.step, steps, warmup)
+    # the headline region keeps its HIP events; the 64-stream region, whose kernel table comes from the pass below, does not
+    elapsed, prof = timed(rk, L.step, steps, warmup, events=(leg == "main" or not overlap))
     k_elapsed, k_steps = elapsed, steps
     note = "kernel durations from the timed region itself (one stream)"
     if overlap:
@@ -441,7 +444,42 @@ def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg, over
     tracks = {"mean_tracked": tracked, "mean_points": points}
     if leg == "main" and steps >= 50:  # not in the few-step counter passes: their per-kernel averages are the step's launches
         tracks["klt_with_err_output"] = klt_full_call_ms(L)
+    if steps >= 50:
+        tracks["graph_replay"] = graph_replay(L, batch)
     return elapsed, kernels, roofline_for(kernels, counters, leg, batch), tracks, note
+
+
+def graph_replay(L, batch, reps=40):
+    """The same steps replayed from a HIP graph: one period of the resident-frame cycle (six steps) captured once on a side
+    stream -- the library's own fork to its helper stream and back is captured with it -- and replayed `reps` times.  What a
+    host that submits whole periods gets; never the headline value (the timed region launches every kernel)."""
+    import torch
+    try:
+        period = len(L.order)
+        side = torch.cuda.Stream(device=L.fe.pts.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # the stream's first steps outside a capture: the helper stream is created here
+            for _ in range(period):
+                L.step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(period):
+                L.step()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        per_step = (time.perf_counter() - t0) / (reps * period)
+        del g
+        return {"ms_per_step": per_step * 1e3, "frames_per_s_per_gpu": batch / per_step, "steps": reps * period,
+                "what": "six consecutive steps captured into one HIP graph and replayed (host wall clock, this rank)"}
+    except Exception as e:  # a measurement beside the contract: its failure must not take the line with it
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def klt_full_call_ms(L, reps=10):
@@ -780,7 +818,7 @@ def main():
             U = UploadLeg(host, nb, args.loss, dev)
             capi.set_overlap(overlap)
             steps_up = max(20, args.steps // 4)
-            el_up, _ = timed(rk, U.step, steps_up, max(3, args.warmup // 2))
+            el_up, _ = timed(rk, U.step, steps_up, max(3, args.warmup // 2), events=False)
             out["streams64"]["h2d_inclusive"] = {
                 "value": 64 * steps_up / el_up, "unit": "frames/s", "steps": steps_up, "ms_per_step": el_up / steps_up * 1e3,
                 "upload_bytes_per_step_per_gpu": U.bytes_per_step,
