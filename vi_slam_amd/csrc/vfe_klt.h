@@ -22,7 +22,6 @@ struct KltParams {
      * order[4k .. 4k+3] instead (a permutation of 0 .. n-1; entries past a frame's count are not read).  Results do
      * not depend on it; neighbours in the image share cache lines and tend to need the same number of iterations. */
     const unsigned short* order;
-    int dbg_iters; /* measurement aid: report every point's total iteration count in `err` instead of the residual */
 };
 
 __device__ static inline int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }

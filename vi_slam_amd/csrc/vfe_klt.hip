@@ -13,7 +13,6 @@
  * the detector.
  */
 #include "vfe_klt.h"
-#include <stdlib.h>
 #include <float.h>
 
 __device__ static inline long long wave_sum_i64(long long v) {
@@ -271,11 +270,8 @@ extern "C" int vfe_dev_klt_track_ws(const vfe_dimg* prev_levels, const vfe_dimg*
         VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
         const int batch = prev_levels[0].batch;
         VFE_REQUIRE(batch > 0 && workspace_bytes >= vfe_klt_track_workspace(pts_cap, batch), "workspace too small");
-        /* measurement aid: VFE_KLT_ORDER_GIVEN=1 takes the order the caller has left in the workspace */
-        static const int order_given = [] { const char* e = getenv("VFE_KLT_ORDER_GIVEN"); return e ? atoi(e) : 0; }();
-        int rc = order_given ? VFE_OK
-                             : klt_order_launch(prev_pts, n_pts, pts_cap, batch, prev_levels[0].width, prev_levels[0].height, nlevels,
-                                                (unsigned short*)workspace, (hipStream_t)stream);
+        int rc = klt_order_launch(prev_pts, n_pts, pts_cap, batch, prev_levels[0].width, prev_levels[0].height, nlevels,
+                                  (unsigned short*)workspace, (hipStream_t)stream);
         if (rc) return rc;
         order = (const unsigned short*)workspace;
     }
@@ -313,8 +309,6 @@ int klt_track_ordered(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, 
     p.win = win; p.max_iter = max_iter; p.epsilon = eps * eps; p.min_eig_thr = min_eig_thr;
     p.use_initial = use_initial_flow ? 1 : 0;
     p.order = win == 21 ? order : nullptr; /* the generic kernel keeps the given order */
-    static const int dbg_iters = [] { const char* e = getenv("VFE_KLT_DEBUG_ITERS"); return e ? atoi(e) : 0; }();
-    p.dbg_iters = dbg_iters;
     const int PW = win + 3, DW = win + 1;
     const size_t smem = ((PW * PW + 15) & ~15) + (size_t)DW * DW * 4 + (size_t)((win * win + 1) & ~1) * 2 + (size_t)win * win * 4;
     ProfScope prof(VFE_K_KLT, (hipStream_t)stream);

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
         const size_t o = (size_t)b * p.cap + pt;
         const float ppx = p.prev_pts[2 * o], ppy = p.prev_pts[2 * o + 1];
         float outx = p.use_initial ? p.next_pts[2 * o] : 0.f, outy = p.use_initial ? p.next_pts[2 * o + 1] : 0.f;
-        int status = 1, itsum = 0;
+        int status = 1;
         float errv = 0.f;
 
         for (int level = max_level; level >= 0; level--) {
@@ -450,7 +450,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
                 }
                 pdx = dx; pdy = dy;
                 j++;
-                itsum++;
                 if (done || j == p.max_iter) {
                     /* last pass: only the residual at the final position, and only where it is reported */
                     if (!(status && level == 0 && p.err)) break;
@@ -467,7 +466,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
         if (sub == 0) {
             p.next_pts[2 * o] = outx; p.next_pts[2 * o + 1] = outy;
             p.status[o] = (uint8_t)status;
-            if (p.err) p.err[o] = p.dbg_iters ? (float)itsum : errv;
+            if (p.err) p.err[o] = errv;
         }
     }
 }
