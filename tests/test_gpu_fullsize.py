@@ -73,6 +73,36 @@ def test_pyramid_1080p_levels_and_border(cuda):
             assert np.array_equal(a[i].cpu().numpy(), r)
 
 
+def test_pyramid_256_streams_one_launch_equals_one_launch_per_level(cuda, monkeypatch):
+    """The headline batch (256 frames of 1080p): the one-launch pyramid and the per-level kernels write the same bytes, levels
+    and reflect-101 borders alike; frames 0, 100 and 255 also against the oracle."""
+    import torch
+    rng = np.random.default_rng(5)
+    base = [synth.scene(synth.BASE_SEED + 20 + i, W, H, i % 4) for i in range(4)] + [synth.noise(90 + i, W, H) for i in range(2)]
+    t = capi.alloc_image(256, H, W, cuda)
+    for i in range(256):
+        t[i].copy_(torch.from_numpy(np.roll(base[i % 6], int(rng.integers(0, 64)), axis=1)).to(cuda))
+    B = capi.LK_BORDER
+
+    def padded(lv):
+        out = []
+        for x in lv[1:]:
+            b, lh, lw = x.shape
+            out.append(x.as_strided((b, lh + 2 * B, lw + 2 * B), x.stride(), x.storage_offset() - B * x.stride(1) - B).clone())
+        return out
+
+    one = padded(capi.build_pyramid(capi.alloc_pyramid(t, 4)))
+    monkeypatch.setenv("VFE_PYR3_MIN_BLOCKS", str(10 ** 9))
+    per_level = padded(capi.build_pyramid(capi.alloc_pyramid(t, 4)))
+    for l, (a, c) in enumerate(zip(one, per_level), start=1):
+        assert torch.equal(a, c), f"level {l}"
+    for i in (0, 100, 255):
+        ref = t[i].cpu().numpy()
+        for l in range(3):
+            ref = ora.pyr_down(ref)
+            assert np.array_equal(one[l][i].cpu().numpy(), np.pad(ref, B, mode="reflect")), f"frame {i} level {l + 1}"
+
+
 def test_orb_1080p_2000_keypoints(cuda):
     """configs[2]: 8-level ORB, 2000 keypoints, on a 1080p frame: keypoints, angles, responses and
     descriptors equal the oracle's."""
