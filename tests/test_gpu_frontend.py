@@ -122,7 +122,7 @@ def test_pyramid_three_levels_per_launch(cuda, w, h, levels, frames, monkeypatch
 
 
 @pytest.mark.parametrize("padded", [True, False])
-def test_klt_border_points_padded_and_unpadded(cuda, padded):
+def test_klt_border_points_padded_and_unpadded(cuda, padded, klt_kernel):
     """Points whose windows overhang every side of the image, at every level: identical results with
     bordered levels (direct reads) and plain levels (reflected reads), both equal to the oracle."""
     import torch
@@ -266,7 +266,7 @@ def test_good_features_with_seeds(cuda):
 
 
 @pytest.mark.parametrize("w,h,levels,npts", [(752, 480, 3, 150), (320, 240, 4, 80), (1920, 1080, 4, 300)])
-def test_klt_parity(cuda, w, h, levels, npts):
+def test_klt_parity(cuda, w, h, levels, npts, klt_kernel):
     import torch
     seqs = [(synth.BASE_SEED + s) for s in range(2)]
     prev = [synth.scene(s, w, h, 0) for s in seqs]
@@ -303,7 +303,7 @@ def test_klt_parity(cuda, w, h, levels, npts):
         assert np.abs(np.median(flow, axis=0) - [-1.5, -0.75]).max() < 0.5
 
 
-def test_klt_forward_backward_check(cuda):
+def test_klt_forward_backward_check(cuda, klt_kernel):
     """Forward track + backward track from the original positions (OPTFLOW_USE_INITIAL_FLOW) + distance
     test: statuses, forward and recovered positions equal the oracle's composition of the same steps."""
     import torch
@@ -721,7 +721,7 @@ def test_frontend_step_fast_grid_bit_exact(cuda):
 
 
 @pytest.mark.parametrize("w,h,levels,npts,win", [(752, 480, 3, 150, 21), (1920, 1080, 4, 600, 21), (640, 480, 3, 100, 15)])
-def test_klt_track_with_workspace_gives_the_same_results(cuda, w, h, levels, npts, win):
+def test_klt_track_with_workspace_gives_the_same_results(cuda, w, h, levels, npts, win, klt_kernel):
     """vfe_dev_klt_track_ws tracks a frame's points in its own order (rim class, then tile); every result lands at its
     point's index, bit for bit what vfe_dev_klt_track and the oracle give -- points on and beyond the rim, ragged
     counts, the err output, and a window size for which the workspace is ignored."""

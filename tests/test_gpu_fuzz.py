@@ -66,7 +66,7 @@ def test_fuzz_pyramid_fast_gftt(cuda, case):
 
 
 @pytest.mark.parametrize("case", range(8 * SCALE))
-def test_fuzz_klt(cuda, case):
+def test_fuzz_klt(cuda, case, klt_kernel):
     import torch
     rng = np.random.default_rng(2000 + case)
     w, h = int(rng.integers(64, 500)), int(rng.integers(64, 300))

@@ -36,6 +36,9 @@ __device__ static inline void bilinear_weights(float a, float b, int& w00, int& 
 
 /* enqueue the 21x21 kernel for p.total_work (frame, point) items */
 void klt21_launch(const KltParams& p, hipStream_t stream);
+/* whether klt21_launch takes its one-wave-per-point kernel for this many (frame, point) slots; that kernel has a
+ * workgroup per point, so a processing order buys nothing there */
+bool klt21_one_wave_per_point(unsigned total_work);
 
 /* vfe_dev_klt_track with an optional processing order (see KltParams::order) */
 int klt_track_ordered(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,

@@ -270,10 +270,13 @@ extern "C" int vfe_dev_klt_track_ws(const vfe_dimg* prev_levels, const vfe_dimg*
         VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
         const int batch = prev_levels[0].batch;
         VFE_REQUIRE(batch > 0 && workspace_bytes >= vfe_klt_track_workspace(pts_cap, batch), "workspace too small");
-        int rc = klt_order_launch(prev_pts, n_pts, pts_cap, batch, prev_levels[0].width, prev_levels[0].height, nlevels,
-                                  (unsigned short*)workspace, (hipStream_t)stream);
-        if (rc) return rc;
-        order = (const unsigned short*)workspace;
+        /* (the kernel for small launches has a workgroup per point: no order to choose) */
+        if (!klt21_one_wave_per_point((unsigned)((size_t)pts_cap * (size_t)batch > 0xFFFFFFFFu ? 0xFFFFFFFFu : (size_t)pts_cap * (size_t)batch))) {
+            int rc = klt_order_launch(prev_pts, n_pts, pts_cap, batch, prev_levels[0].width, prev_levels[0].height, nlevels,
+                                      (unsigned short*)workspace, (hipStream_t)stream);
+            if (rc) return rc;
+            order = (const unsigned short*)workspace;
+        }
     }
     return klt_track_ordered(prev_levels, next_levels, nlevels, prev_pts, n_pts, pts_cap, next_pts, status, err, win, max_iter, eps,
                              min_eig_thr, use_initial_flow, order, (hipStream_t)stream);

@@ -32,6 +32,7 @@
  * float that the CPU code performs on its 64-bit sum. */
 #include "vfe_klt.h"
 #include <float.h>
+#include <stdlib.h>
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
@@ -471,7 +472,225 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
     }
 }
 
+
+/* ---- one wavefront per point --------------------------------------------------------------------------------------
+ * For launches with so few points that four per wave leave most of the chip's SIMDs without a wave, the time of the
+ * launch is the time of one wave, and that is the number of instructions on a point's path.  Here the 441 pixels of a
+ * point are spread over 63 lanes instead of 16: lane l owns the single piece (window row l / 3, columns 8 * (l % 3) ..)
+ * of 8, 8 or 5 pixels; lane 63 shadows lane 62 and is left out of the sums.  Same arithmetic, same exact integer
+ * window sums, same order of the floating-point operations on them: results are those of k_klt21 bit for bit. */
+__device__ static inline int wave_sum(int v) {
+    v = row_sum(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+__device__ static inline float wave_sum_to_float(int v) {
+    const int lo = wave_sum(v & 0xFFFF), hi = wave_sum(v >> 16);
+    return __builtin_fmaf((float)hi, 65536.f, (float)lo);
+}
+/* lane (row, pk) requests bytes 8*pk .. 8*pk+7 of patch row `row` (0..20) and, the first lanes, of the rows from 21 on */
+struct WideLane { int row, pk; bool on; };
+template <int NROWS>
+__device__ static inline void fetch_patch_wide(const DImg& im, const uint8_t* fp, int x0, int y0, const WideLane& P, uint2 (&v)[2]) {
+    const bool padded = im.border >= KLT_NEED_BORDER;
+    const bool cols_in = padded || (x0 >= 0 && x0 + 24 <= im.w);
+    const bool inside = cols_in && (padded || (y0 >= 0 && y0 + NROWS <= im.h)); /* the same for every lane */
+    const int x = x0 + 8 * P.pk;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = P.row + 21 * i;
+        v[i] = make_uint2(0u, 0u);
+        if (!P.on || r >= NROWS) continue;
+        if (inside) { v[i] = ldu64(fp + (ptrdiff_t)(y0 + r) * im.pitch + x); continue; }
+        const int y = padded ? y0 + r : reflect101(y0 + r, im.h);
+        const uint8_t* src = fp + (ptrdiff_t)y * im.pitch;
+        if (cols_in) v[i] = ldu64(src + x);
+        else {
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                lo |= (unsigned)src[reflect101(x + k, im.w)] << (8 * k);
+                hi |= (unsigned)src[reflect101(x + 4 + k, im.w)] << (8 * k);
+            }
+            v[i] = make_uint2(lo, hi);
+        }
+    }
+}
+template <int NROWS>
+__device__ static inline void store_patch_wide(const uint2 (&v)[2], const WideLane& P, unsigned* area) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = P.row + 21 * i;
+        if (P.on && r < NROWS) *reinterpret_cast<uint2*>(area + r * PATCH_ROW_DW + 2 * P.pk) = v[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+__global__ __launch_bounds__(64) void k_klt21_wide(KltParams p) {
+    __shared__ __align__(16) unsigned s_patch[PATCH_DW];
+    __shared__ __align__(16) unsigned s_patch2[PATCH_DW];
+    unsigned* area = s_patch;
+    unsigned* area2 = s_patch2;
+    const int lane = threadIdx.x;
+    const bool counted = lane < 63;
+    WideLane P;
+    P.on = counted;
+    {
+        const int l = counted ? lane : 62;
+        P.row = l / 3; P.pk = l - 3 * P.row;
+    }
+    const int row = P.row, dw = 2 * P.pk, nvalid = P.pk == 2 ? 5 : 8;
+    const int win = 21;
+    const float half = 10.f;
+    const float FLT_SCALE = 1.f / (float)(1 << 20);
+    const int max_level = p.nlevels - 1;
+
+    /* all points of a frame on one XCD, as in k_klt21 (one workgroup per point here) */
+    const unsigned per_frame = (unsigned)max(1, p.cap);
+    const unsigned grouped = p.total_work / (8u * per_frame) * (8u * per_frame);
+    unsigned idx = blockIdx.x;
+    if (idx < grouped) {
+        const unsigned xcd = idx & 7u, slot = idx >> 3, grp = slot / per_frame, within = slot - grp * per_frame;
+        idx = (grp * 8u + xcd) * per_frame + within;
+    }
+    if (idx >= p.total_work) return;
+    const int b = (int)(idx / (unsigned)p.cap), slot = (int)(idx - (unsigned)b * (unsigned)p.cap);
+    const int n = p.n_pts ? min(p.n_pts[b], p.cap) : p.cap;
+    if (slot >= n) {
+        if (lane == 0) { p.status[idx] = 0; if (p.err) p.err[idx] = 0.f; }
+        return;
+    }
+    const int pt = p.order ? (int)p.order[idx] : slot;
+    const size_t o = (size_t)b * p.cap + pt;
+    const float ppx = p.prev_pts[2 * o], ppy = p.prev_pts[2 * o + 1];
+    float outx = p.use_initial ? p.next_pts[2 * o] : 0.f, outy = p.use_initial ? p.next_pts[2 * o + 1] : 0.f;
+    int status = 1;
+    float errv = 0.f;
+
+    for (int level = max_level; level >= 0; level--) {
+        const DImg& I = p.prev[level];
+        const DImg& J = p.next[level];
+        const uint8_t* ip = I.frame(b);
+        const uint8_t* jp = J.frame(b);
+        const float sc = __uint_as_float((unsigned)(127 - level) << 23); /* 2^-level */
+        float px = ppx * sc, py = ppy * sc, nx, ny;
+        if (level == max_level) {
+            if (p.use_initial) { nx = outx * sc; ny = outy * sc; }
+            else { nx = px; ny = py; }
+        } else { nx = outx * 2.f; ny = outy * 2.f; }
+        outx = nx; outy = ny;
+
+        px -= half; py -= half;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -win || ipx >= I.w || ipy < -win || ipy >= I.h) {
+            if (level == 0) { status = 0; errv = 0.f; }
+            continue;
+        }
+        int iw00, iw01, iw10, iw11;
+        bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
+        const unsigned Wt0 = (unsigned)iw00 | ((unsigned)iw10 << 16), Wt1 = (unsigned)iw01 | ((unsigned)iw11 << 16);
+
+        uint2 vI[2], vJ[2];
+        fetch_patch_wide<24>(I, ip, ipx - 1, ipy - 1, P, vI);
+        nx -= half; ny -= half;
+        float qx = nx, qy = ny;
+        int inx = (int)floorf(qx), iny = (int)floorf(qy);
+        bool inr = !(inx < -win || inx >= J.w || iny < -win || iny >= J.h);
+        if (inr) fetch_patch_wide<22>(J, jp, inx, iny, P, vJ);
+
+        unsigned Tx[4], Ty[4];
+        int a11 = 0, a12 = 0, a22 = 0, c1 = 0, c2 = 0;
+        {
+            store_patch_wide<24>(vI, P, area);
+            const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < I.w && ipy + win < I.h;
+            unsigned w[4][3];
+            PieceCarry carry;
+            read_piece<4>(area, row, dw, w);
+            if (interior)
+                piece_template<8, false, false, false>(w, Wt0, Wt1, true, ipx + 4 * dw, ipy + row, I.w, I.h, nvalid, Tx, Ty, a11, a12, a22, c1, c2, carry);
+            else
+                piece_template<8, true, false, false>(w, Wt0, Wt1, false, ipx + 4 * dw, ipy + row, I.w, I.h, nvalid, Tx, Ty, a11, a12, a22, c1, c2, carry);
+            if (!counted) { a11 = 0; a12 = 0; a22 = 0; c1 = 0; c2 = 0; }
+        }
+        const float A11 = wave_sum_to_float(a11) * FLT_SCALE, A12 = wave_sum_to_float(a12) * FLT_SCALE,
+                    A22 = wave_sum_to_float(a22) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+        if ((double)minEig < p.min_eig_thr || D < FLT_EPSILON) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        D = 1.f / D;
+        float pdx = 0.f, pdy = 0.f;
+        bool err_pass = false;
+        bool fresh = true;
+        for (int j = 0;;) {
+            if (!inr) {
+                if (level == 0) status = 0;
+                break;
+            }
+            bilinear_weights(qx - (float)inx, qy - (float)iny, iw00, iw01, iw10, iw11);
+            const unsigned W0 = (unsigned)iw00 | ((unsigned)iw10 << 16), W1 = (unsigned)iw01 | ((unsigned)iw11 << 16);
+            if (fresh) store_patch_wide<22>(vJ, P, area);
+            if (err_pass) {
+                uint2 vT[2];
+                fetch_patch_wide<22>(I, ip, ipx, ipy, P, vT);
+                store_patch_wide<22>(vT, P, area2);
+                int es = piece_residual<8>(area, area2, row, dw, nvalid, W0, W1, Wt0, Wt1);
+                if (!counted) es = 0;
+                errv = (float)wave_sum(es) * 1.f / (float)(32 * win * win);
+                break;
+            }
+            int b1 = 0, b2 = 0;
+            piece_pass<8>(area, row, dw, W0, W1, Tx, Ty, b1, b2);
+            if (!counted) { b1 = 0; b2 = 0; }
+            const float fb1 = wave_sum_to_float(b1 - c1) * FLT_SCALE, fb2 = wave_sum_to_float(b2 - c2) * FLT_SCALE;
+            const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
+            nx += dx; ny += dy;
+            outx = nx + half; outy = ny + half;
+            bool done = ((double)dx * (double)dx + (double)dy * (double)dy <= p.epsilon);
+            const float kSmall = 0.01f; /* see k_klt21 */
+            if (!done && j > 0 && fabsf(dx + pdx) <= kSmall && fabsf(dy + pdy) <= kSmall) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                done = true;
+            }
+            pdx = dx; pdy = dy;
+            j++;
+            if (done || j == p.max_iter) {
+                if (!(status && level == 0 && p.err)) break;
+                err_pass = true;
+                qx = outx - half; qy = outy - half;
+            } else { qx = nx; qy = ny; }
+            const int ninx = (int)floorf(qx), niny = (int)floorf(qy);
+            fresh = ninx != inx || niny != iny;
+            inx = ninx; iny = niny;
+            inr = !(inx < -win || inx >= J.w || iny < -win || iny >= J.h);
+            if (inr && fresh) fetch_patch_wide<22>(J, jp, inx, iny, P, vJ);
+        }
+    }
+    if (lane == 0) {
+        p.next_pts[2 * o] = outx; p.next_pts[2 * o + 1] = outy;
+        p.status[o] = (uint8_t)status;
+        if (p.err) p.err[o] = errv;
+    }
+}
+
+/* Launches of at most this many (frame, point) slots take one wave per point.  Measured on 1080p pairs with 1000 points
+ * per frame, tracker alone, four points per wave against one: 1 frame 47 -> 32 us, 2 frames 58 -> 35, 4 frames 65 -> 52,
+ * 8 frames 69 -> 82 (from there on the chip is full either way and the quarter-filled lanes of the scalar work cost more
+ * than the shorter path saves).  VFE_KLT_WIDE_MAX overrides the limit for measurements; it is read at every call. */
+#define KLT21_WIDE_MAX 5000u
+bool klt21_one_wave_per_point(unsigned total_work) {
+    const char* e = getenv("VFE_KLT_WIDE_MAX");
+    return total_work <= (e ? (unsigned)strtoul(e, nullptr, 10) : KLT21_WIDE_MAX);
+}
+
 void klt21_launch(const KltParams& p, hipStream_t stream) {
+    if (klt21_one_wave_per_point(p.total_work)) {
+        hipLaunchKernelGGL(k_klt21_wide, dim3(p.total_work), dim3(64), 0, stream, p);
+        return;
+    }
     const unsigned items = (p.total_work + 3u) / 4u;
     if (items <= (1u << 20)) hipLaunchKernelGGL(k_klt21<true>, dim3(items), dim3(64), 0, stream, p);
     else hipLaunchKernelGGL(k_klt21<false>, dim3(1u << 20), dim3(64), 0, stream, p);
