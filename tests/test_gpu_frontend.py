@@ -170,6 +170,18 @@ def test_packed_sqrt_correctly_rounded_everywhere(cuda):
     assert "packed rsq refinement 0" in r.stdout, r.stdout
 
 
+def test_selection_register_sort_against_std_sort(cuda):
+    """The selection kernel's sort of up to 1024 keys held one per thread (lane exchanges within a wave, LDS beyond)
+    against std::sort: every size 64 .. 1024, random keys, keys differing in one half only, runs of equal keys, zero
+    padding (the program is built by `make` from tests/hip/check_sort.hip)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "bin", "check_sort")
+    assert os.path.exists(exe), "run `make` first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 of 240 arrays wrong" in r.stdout, r.stdout
+
+
 def test_eigen_pass_every_band_tail(cuda):
     """The eigenvalue kernel walks bands of rows three at a time and finishes each band with up to four single steps,
     the last two of the bottom band with the out-of-image rows: every height from 17 to 52 exercises every remainder,

@@ -20,14 +20,16 @@
  * sets are bit-exact.
  */
 #include "vfe_gftt.h"
+#include "vfe_sort.h"
 
 #define SEL_THREADS 1024
 #define SEL_M 8192
-#define SEED_CELLS 8192 /* LDS grid of tracked points: heads + two node arrays alias the 64 KiB sort buffer */
+#define SEED_CELLS 8192 /* LDS grid of tracked points: cell words + nodes alias the 64 KiB sort buffer */
 #define SEED_NODES 4096
 #define SEL_M_FIRST 2048 /* first batch of the ordered walk: usually enough, and sorts 5x faster than a full one */
 #define WALK_CELLS 24576 /* LDS min-distance grid of the corners accepted in this call */
 #define WALK_NODES 4096
+#define KEY_REGS 9 /* candidate keys a thread of the selection holds in registers */
 
 struct SelParams {
     int W, H, max_corners;
@@ -94,37 +96,59 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
     __shared__ u32 s_cnt;
     __shared__ u32 s_dmin;
     __shared__ int s_nacc;
-    __shared__ unsigned short w_heads[WALK_CELLS]; /* 0 = empty, else node + 1 */
-    __shared__ u32 w_xy[WALK_NODES];               /* x | y << 16 */
-    __shared__ unsigned short w_next[WALK_NODES];
+    /* first the pool through which the valid keys reach the threads' registers, then the walk's grid */
+    __shared__ u64 s_pool[KEY_REGS * SEL_THREADS];
+    unsigned short* w_heads = reinterpret_cast<unsigned short*>(s_pool);            /* [WALK_CELLS] 0 = empty, else node + 1 */
+    u32* w_xy = reinterpret_cast<u32*>(w_heads + WALK_CELLS);                       /* [WALK_NODES] x | y << 16 */
+    unsigned short* w_next = reinterpret_cast<unsigned short*>(w_xy + WALK_NODES);  /* [WALK_NODES] */
+    static_assert(WALK_CELLS * 2 + WALK_NODES * 6 <= sizeof(u64) * KEY_REGS * SEL_THREADS, "the walk's grid fits the pool");
 
     const int b = blockIdx.x, tid = threadIdx.x;
     __shared__ u32 s_segn[GF_NSEG];
     if (tid < GF_NSEG) s_segn[tid] = min(p.cand_count[(b * GF_NSEG + tid) * GF_CSTRIDE], p.seg_cap);
     u64* keys = p.cand + (size_t)b * GF_NSEG * p.seg_cap;
     __syncthreads();
-    /* Every pass below visits all candidate keys of the frame.  The first SEL_THREADS keys of each segment (all of
-     * them unless the frame is unusually busy) are loaded once, one per thread and segment, and live in registers;
-     * only the rest is re-read from memory.  f(key, slot) returns true to clear the key (0 = no key). */
-    u64 rk[GF_NSEG];
+    /* Every pass below visits all candidate keys of the frame that pass the exact threshold.  The frame's segments are
+     * taken as one list; its first KEY_REGS * SEL_THREADS keys (a 1080p frame has ~9000, half of them above the
+     * threshold) are loaded once, and those above the threshold are packed through LDS into as few register slots per
+     * thread as they need -- every pass then runs over about five full slots per thread instead of ten half-empty
+     * ones.  Only a busier frame's rest stays in memory and is re-read by every pass, four loads in flight.
+     * f(key) returns true to clear the key (0 = no key). */
+    u32 seg_at[GF_NSEG + 1]; /* where each segment starts in the list */
+    seg_at[0] = 0;
 #pragma unroll
-    for (int sg = 0; sg < GF_NSEG; sg++) rk[sg] = (u32)tid < s_segn[sg] ? keys[(size_t)sg * p.seg_cap + tid] : 0ull;
+    for (int sg = 0; sg < GF_NSEG; sg++) seg_at[sg + 1] = seg_at[sg] + s_segn[sg];
+    const u32 n_keys = seg_at[GF_NSEG];
+    auto key_at = [&](u32 g) -> u64* { /* g < n_keys */
+        u32 sg = 0, at = 0;
+#pragma unroll
+        for (int k = 1; k < GF_NSEG; k++)
+            if (g >= seg_at[k]) { sg = (u32)k; at = seg_at[k]; }
+        return keys + (size_t)sg * p.seg_cap + (g - at);
+    };
+    u64 rk[KEY_REGS];
+#pragma unroll
+    for (int j = 0; j < KEY_REGS; j++) rk[j] = (u32)tid + j * SEL_THREADS < n_keys ? *key_at((u32)tid + j * SEL_THREADS) : 0ull;
+    u32 n_pool = 0; /* keys in registers: slot j of thread t holds key t + j * SEL_THREADS of the pool */
+    auto for_each_key_in_memory = [&](auto&& f) {
+        for (u32 i = tid + KEY_REGS * SEL_THREADS; i < n_keys; i += 4 * SEL_THREADS) {
+            u64* kp[4];
+            u64 k[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                kp[j] = i + j * SEL_THREADS < n_keys ? key_at(i + j * SEL_THREADS) : nullptr;
+                k[j] = kp[j] ? *kp[j] : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (k[j] != 0ull && f(k[j])) *kp[j] = 0ull;
+        }
+    };
     auto for_each_key = [&](auto&& f) {
 #pragma unroll
-        for (int sg = 0; sg < GF_NSEG; sg++) {
-            if (rk[sg] != 0ull && f(rk[sg])) rk[sg] = 0ull;
-            const u32 cn = s_segn[sg];
-            u64* kp = keys + (size_t)sg * p.seg_cap;
-            /* four loads in flight: one after the other, a busy segment costs a round trip to L2 per 1024 keys */
-            for (u32 i = tid + SEL_THREADS; i < cn; i += 4 * SEL_THREADS) {
-                u64 k[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) k[j] = i + j * SEL_THREADS < cn ? kp[i + j * SEL_THREADS] : 0ull;
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (k[j] != 0ull && f(k[j])) kp[i + j * SEL_THREADS] = 0ull;
-            }
-        }
+        for (int j = 0; j < KEY_REGS; j++)
+            if ((u32)j * SEL_THREADS < n_pool && rk[j] != 0ull && f(rk[j])) rk[j] = 0ull;
+        for_each_key_in_memory(f);
     };
     const float maxv = __uint_as_float(p.frame_max[b * GF_CSTRIDE]);
     const float thr = (float)((double)maxv * p.quality);
@@ -184,76 +208,180 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
      * and are checked there as well. */
     const bool lds_walk = p.use_grid && cells <= WALK_CELLS && limit <= WALK_NODES;
     const bool global_grid = p.use_grid && (!lds_walk || (ns > 0 && !lds_seeds));
+    {
+        /* pack the keys above the threshold: a reservation per wave and slot, order does not matter */
+        const int lane = tid & 63;
+        __syncthreads(); /* s_cnt is zero */
+#pragma unroll
+        for (int j = 0; j < KEY_REGS; j++) {
+            const bool valid = rk[j] > lowkey;
+            const u64 bm = __ballot(valid);
+            if (bm == 0) continue;
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt, (u32)__popcll(bm));
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            if (valid) s_pool[base + __popcll(bm & ((1ull << lane) - 1ull))] = rk[j];
+        }
+        __syncthreads();
+        n_pool = s_cnt;
+#pragma unroll
+        for (int j = 0; j < KEY_REGS; j++) rk[j] = (u32)tid + j * SEL_THREADS < n_pool ? s_pool[tid + j * SEL_THREADS] : 0ull;
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
+    }
     if (lds_walk)
         for (int c = tid; c < cells; c += SEL_THREADS) w_heads[c] = 0;
-    u32* g_heads = reinterpret_cast<u32*>(s_keys);       /* [SEED_CELLS] 0 = empty, else node + 1 */
-    u32* g_xy = g_heads + SEED_CELLS;                    /* [SEED_NODES] x | y << 16 */
-    u32* g_next = g_xy + SEED_NODES;                     /* [SEED_NODES] */
+    /* LDS grid of the tracked points (aliases the sort buffer).  A cell word holds the head of the cell's chain in its low
+     * half (node + 1, 0 = empty) and, in its high half, nine bits that say which cells of its 3x3 neighbourhood hold any
+     * tracked point (bit 3 (dy + 1) + dx + 1): a candidate reads its own cell's word and then only the occupied
+     * neighbours -- none at all for a candidate with no tracked point near it. */
+    u32* g_cell = reinterpret_cast<u32*>(s_keys);                  /* [SEED_CELLS] */
+    u64* g_node = reinterpret_cast<u64*>(g_cell + SEED_CELLS);     /* [SEED_NODES] x | y << 16 | (u64)next << 32 */
+    static_assert(SEED_CELLS * sizeof(u32) + SEED_NODES * sizeof(u64) <= sizeof(u64) * SEL_M, "the grid aliases the sort buffer");
+    static_assert(SEED_NODES % SEL_THREADS == 0 && SEED_NODES < 65536, "node numbers fit the low half of a cell word");
+    auto build_track_grid = [&]() { /* the caller puts a barrier behind it */
+        const float* sd = p.seeds + (size_t)b * p.seed_cap * 2;
+        for (int c = tid; c < cells; c += SEL_THREADS) g_cell[c] = 0;
+        __syncthreads();
+        u32 sq[SEED_NODES / SEL_THREADS]; /* this thread's points, ~0 = none */
+#pragma unroll
+        for (int j = 0; j < SEED_NODES / SEL_THREADS; j++) {
+            const int s = tid + j * SEL_THREADS;
+            sq[j] = ~0u;
+            if (s >= ns) continue;
+            const int sx = __float2int_rn(sd[2 * s]), sy = __float2int_rn(sd[2 * s + 1]);
+            if (sx < 0 || sy < 0 || sx >= p.W || sy >= p.H) continue;
+            sq[j] = (u32)sx | ((u32)sy << 16);
+            const int c = cell_of(sy, p.cell, p.cell_magic) * p.gw + cell_of(sx, p.cell, p.cell_magic);
+            g_node[s] = (u64)sq[j] | ((u64)atomicExch(&g_cell[c], (u32)s + 1) << 32); /* the high halves are still zero */
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SEED_NODES / SEL_THREADS; j++) {
+            if (sq[j] == ~0u) continue;
+            const int xc = cell_of((int)(sq[j] & 0xFFFFu), p.cell, p.cell_magic), yc = cell_of((int)(sq[j] >> 16), p.cell, p.cell_magic);
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                const int yy = yc - 1 + c / 3, xx = xc - 1 + c % 3;
+                /* seen from the cell (yy, xx) this point's cell is the neighbour 8 - c */
+                if (yy >= 0 && yy < p.gh && xx >= 0 && xx < p.gw) atomicOr(&g_cell[yy * p.gw + xx], 1u << (16 + 8 - c));
+            }
+        }
+    };
     if (p.use_grid && ns > 0) {
         const float* sd = p.seeds + (size_t)b * p.seed_cap * 2;
         if (lds_seeds) {
-            for (int c = tid; c < cells; c += SEL_THREADS) g_heads[c] = 0;
-            __syncthreads();
-        }
-        for (int s = tid; s < ns; s += SEL_THREADS) {
-            const int sx = __float2int_rn(sd[2 * s]), sy = __float2int_rn(sd[2 * s + 1]);
-            if (sx < 0 || sy < 0 || sx >= p.W || sy >= p.H) continue;
-            const int c = cell_of(sy, p.cell, p.cell_magic) * p.gw + cell_of(sx, p.cell, p.cell_magic);
-            if (lds_seeds) {
-                g_xy[s] = (u32)sx | ((u32)sy << 16);
-                g_next[s] = atomicExch(&g_heads[c], (u32)s + 1);
-            } else {
+            build_track_grid();
+        } else {
+            for (int s = tid; s < ns; s += SEL_THREADS) {
+                const int sx = __float2int_rn(sd[2 * s]), sy = __float2int_rn(sd[2 * s + 1]);
+                if (sx < 0 || sy < 0 || sx >= p.W || sy >= p.H) continue;
+                const int c = cell_of(sy, p.cell, p.cell_magic) * p.gw + cell_of(sx, p.cell, p.cell_magic);
                 st_agent(&node_xy[s], (u32)sx | ((u32)sy << 16));
                 const u32 old = atomicExch(&heads[c], (u32)s + 1);
                 st_agent(&node_next[s], old);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
-    /* how many candidates pass the exact threshold (and are not blocked by a tracked point) */
-    u32 mine = 0;
-    if (lds_seeds) {
+    /* one candidate against the grid of tracked points: its own cell's word, then the chains of the occupied neighbours */
+    auto blocked_by_track = [&](u64 k) {
+        const int y = (int)(((u32)k) >> 16), x = (int)(((u32)k) & 0xFFFFu);
+        const int xc = cell_of(x, p.cell, p.cell_magic), yc = cell_of(y, p.cell, p.cell_magic);
+        const int at = yc * p.gw + xc;
+        const u32 own = g_cell[at];
+        for (u32 m = own >> 16; m; m &= m - 1) {
+            const int c = __builtin_ctz(m);
+            u32 n = (c == 4 ? own : g_cell[at + (c / 3 - 1) * p.gw + c % 3 - 1]) & 0xFFFFu;
+            while (n) {
+                const u64 nd = g_node[n - 1];
+                const int dx = x - (int)((u32)nd & 0xFFFFu), dy = y - (int)((u32)nd >> 16);
+                if ((u32)(dx * dx + dy * dy) < p.md2i) return true;
+                n = (u32)(nd >> 32);
+            }
+        }
+        return false;
+    };
+    __shared__ u32 s_total;
+    auto block_total = [&](u32 v) { /* sum over the workgroup, in every thread */
+        const u32 t = block_suffix_scan(v, s_scan); /* the sum, at thread 0 */
+        if (tid == 0) s_total = t;
+        __syncthreads();
+        const u32 r = s_total;
+        __syncthreads();
+        return r;
+    };
+    /* clears the keys in (above, below) that a tracked point blocks; returns how many are left there */
+    auto test_against_tracks = [&](u64 above, u64 below) {
+        u32 left = 0;
         for_each_key([&](u64 k) {
-            if (!(k > lowkey)) return false;
-            const int y = (int)(((u32)k) >> 16), x = (int)(((u32)k) & 0xFFFFu);
-            const int xc = cell_of(x, p.cell, p.cell_magic), yc = cell_of(y, p.cell, p.cell_magic);
-            const int x1 = max(0, xc - 1), x2 = min(p.gw - 1, xc + 1);
-            const int y1 = max(0, yc - 1), y2 = min(p.gh - 1, yc + 1);
-            /* all nine cell heads first, then the (short) chains side by side */
-            u32 hd[9];
-#pragma unroll
-            for (int c = 0; c < 9; c++) {
-                const int yy = yc - 1 + c / 3, xx = xc - 1 + c % 3;
-                hd[c] = (yy >= y1 && yy <= y2 && xx >= x1 && xx <= x2) ? g_heads[yy * p.gw + xx] : 0u;
-            }
-            bool blocked = false, more = true;
-            while (more && !blocked) {
-                more = false;
-#pragma unroll
-                for (int c = 0; c < 9; c++)
-                    if (hd[c]) {
-                        const u32 q = g_xy[hd[c] - 1];
-                        const u32 nx = g_next[hd[c] - 1];
-                        const int dx = x - (int)(q & 0xFFFF), dy = y - (int)(q >> 16);
-                        if ((u32)(dx * dx + dy * dy) < p.md2i) blocked = true;
-                        hd[c] = nx;
-                        more = more || nx != 0;
-                    }
-            }
-            if (!blocked) mine++;
+            if (!(k > above && k < below)) return false;
+            const bool blocked = blocked_by_track(k);
+            if (!blocked) left++;
             return blocked;
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return block_total(left);
+    };
+    /* MSD radix select: the lowest T such that at most m keys lie in [T, below), among the keys above `above` (T > above) */
+    auto radix_select = [&](u64 above, u64 below, u32 m) {
+        /* keys are compared on bits [hi_shift, 64) against prefix; valid keys lie between the threshold and the
+         * frame maximum, so the bits those two share need no pass */
+        const u32 diff = __float_as_uint(thr) ^ __float_as_uint(maxv);
+        int hi_shift = diff ? 64 - __clz((int)diff) : 32;
+        u64 prefix = hi_shift == 64 ? 0ull : (((u64)__float_as_uint(maxv) << 32) >> hi_shift);
+        u64 T = 0;
+        for (;;) {
+            const int bits = hi_shift >= 11 ? 11 : hi_shift;
+            const int shift = hi_shift - bits;
+            const u32 nb = 1u << bits;
+            for (u32 i = tid; i <= 2048; i += SEL_THREADS) s_hist[i] = 0;
+            __syncthreads();
+            for_each_key([&](u64 k) {
+                if (k > above && k < below && (hi_shift == 64 || (k >> hi_shift) == prefix))
+                    atomicAdd(&s_hist[(u32)(k >> shift) & (nb - 1)], 1u);
+                return false;
+            });
+            __syncthreads();
+            const u32 h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+            const u32 ss = block_suffix_scan(h0 + h1, s_scan);
+            /* S(d) = number of keys in bins >= d */
+            s_hist[2 * tid] = ss;
+            s_hist[2 * tid + 1] = ss - h0;
+            if (tid == 0) s_hist[2048] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32 d = 2 * tid + q;
+                if (s_hist[d] <= m && (d == 0 || s_hist[d - 1] > m)) s_dmin = d;
+            }
+            if (tid == 0 && s_hist[2047] > m) s_dmin = 2048;
+            __syncthreads();
+            const u32 dmin = s_dmin;
+            const u32 taken = s_hist[dmin];
+            __syncthreads();
+            if (taken > 0 || dmin == 0) {
+                T = (hi_shift == 64 ? 0ull : (prefix << hi_shift)) | ((u64)dmin << shift);
+                break;
+            }
+            /* bin dmin-1 alone holds more than m keys: refine inside it */
+            prefix = (hi_shift == 64 ? 0ull : (prefix << bits)) | (u64)(dmin - 1);
+            hi_shift = shift;
+        }
+        return T <= above ? above + 1 : T;
+    };
+
+    /* how many candidates pass the exact threshold and are not blocked by a tracked point */
+    u32 total;
+    if (lds_seeds) {
+        total = test_against_tracks(lowkey, ~0ull);
     } else {
+        u32 mine = 0;
         for_each_key([&](u64 k) { mine += (k > lowkey) ? 1u : 0u; return false; });
+        total = block_total(mine);
     }
-    const u32 total_valid = block_suffix_scan(mine, s_scan) /* value at tid 0 */;
-    __shared__ u32 s_total;
-    if (tid == 0) s_total = total_valid;
-    __syncthreads();
-    const u32 total = s_total;
 
     u64 U = ~0ull; /* exclusive upper bound of keys not yet consumed */
     u32 consumed = 0;
@@ -262,56 +390,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
      * third of the time, and a further batch follows whenever the first does not fill the budget */
     u32 m_batch = limit <= 64 ? SEL_M_FIRST / 4 : SEL_M_FIRST;
     while (consumed < total && n_acc < limit) {
-        u64 T;
-        if (total - consumed <= m_batch) {
-            T = lowkey + 1;
-        } else {
-            /* MSD radix select: largest top range [T, U) holding <= m_batch keys */
-            /* keys are compared on bits [hi_shift, 64) against prefix; valid keys lie between the threshold and the
-             * frame maximum, so the bits those two share need no pass */
-            const u32 diff = __float_as_uint(thr) ^ __float_as_uint(maxv);
-            int hi_shift = diff ? 64 - __clz((int)diff) : 32;
-            u64 prefix = hi_shift == 64 ? 0ull : (((u64)__float_as_uint(maxv) << 32) >> hi_shift);
-            T = 0;
-            for (;;) {
-                const int bits = hi_shift >= 11 ? 11 : hi_shift;
-                const int shift = hi_shift - bits;
-                const u32 nb = 1u << bits;
-                for (u32 i = tid; i <= 2048; i += SEL_THREADS) s_hist[i] = 0;
-                __syncthreads();
-                for_each_key([&](u64 k) {
-                    if (k > lowkey && k < U && (hi_shift == 64 || (k >> hi_shift) == prefix))
-                        atomicAdd(&s_hist[(u32)(k >> shift) & (nb - 1)], 1u);
-                    return false;
-                });
-                __syncthreads();
-                const u32 h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
-                const u32 ss = block_suffix_scan(h0 + h1, s_scan);
-                /* S(d) = number of keys in bins >= d */
-                s_hist[2 * tid] = ss;
-                s_hist[2 * tid + 1] = ss - h0;
-                if (tid == 0) s_hist[2048] = 0;
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const u32 d = 2 * tid + q;
-                    if (s_hist[d] <= m_batch && (d == 0 || s_hist[d - 1] > m_batch)) s_dmin = d;
-                }
-                if (tid == 0 && s_hist[2047] > m_batch) s_dmin = 2048;
-                __syncthreads();
-                const u32 dmin = s_dmin;
-                const u32 taken = s_hist[dmin];
-                __syncthreads();
-                if (taken > 0 || dmin == 0) {
-                    T = (hi_shift == 64 ? 0ull : (prefix << hi_shift)) | ((u64)dmin << shift);
-                    break;
-                }
-                /* bin dmin-1 alone holds more than m_batch keys: refine inside it */
-                prefix = (hi_shift == 64 ? 0ull : (prefix << bits)) | (u64)(dmin - 1);
-                hi_shift = shift;
-            }
-            if (T <= lowkey) T = lowkey + 1;
-        }
+        const u64 T = total - consumed <= m_batch ? lowkey + 1 : radix_select(lowkey, U, m_batch);
         /* collect [T, U) */
         for_each_key([&](u64 k) {
             if (k >= T && k < U) {
@@ -327,20 +406,25 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
         for (u32 i = taken + tid; i < n2; i += SEL_THREADS) s_keys[i] = 0;
         __syncthreads();
         if (tid == 0) s_cnt = 0;
-        /* bitonic sort, descending: one compare-exchange per thread and step (pair t = elements i and i + j, i = t with
-         * a zero inserted at bit log2 j).  The 64 pairs of a wave stay inside one 128-element block as long as j <= 64,
-         * and a wave's LDS accesses stay in order: only steps that cross blocks, and the last step of a stage, need
-         * the workgroup barrier. */
-        for (u32 k = 2; k <= n2; k <<= 1)
-            for (u32 j = k >> 1; j > 0; j >>= 1) {
-                for (u32 t = tid; t < n2 / 2; t += SEL_THREADS) {
-                    const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-                    const u64 a = s_keys[i], c = s_keys[l];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (a < c) : (a > c)) { s_keys[i] = c; s_keys[l] = a; }
+        const u64* sorted = s_keys;
+        if (n2 <= SEL_THREADS) {
+            sorted = sort1024_desc(s_keys, n2); /* a key per thread, in registers */
+        } else {
+            /* bitonic sort in LDS, descending: one compare-exchange per thread and step (pair t = elements i and i + j,
+             * i = t with a zero inserted at bit log2 j).  The 64 pairs of a wave stay inside one 128-element block as long
+             * as j <= 64, and a wave's LDS accesses stay in order: only steps that cross blocks, and the last step of a
+             * stage, need the workgroup barrier. */
+            for (u32 k = 2; k <= n2; k <<= 1)
+                for (u32 j = k >> 1; j > 0; j >>= 1) {
+                    for (u32 t = tid; t < n2 / 2; t += SEL_THREADS) {
+                        const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                        const u64 a = s_keys[i], c = s_keys[l];
+                        const bool desc = (i & k) == 0;
+                        if (desc ? (a < c) : (a > c)) { s_keys[i] = c; s_keys[l] = a; }
+                    }
+                    if (j > 64 || j == 1) __syncthreads();
                 }
-                if (j > 64 || j == 1) __syncthreads();
-            }
+        }
 
         /* wave-parallel greedy walk over the sorted batch */
         if (tid < 64) {
@@ -349,7 +433,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_gftt_select(SelParams p) {
             for (u32 base = 0; base < taken && acc < limit; base += 64) {
                 const u32 i = base + lane;
                 const bool valid = i < taken;
-                const u64 key = valid ? s_keys[i] : 0ull;
+                const u64 key = valid ? sorted[i] : 0ull;
                 const int y = (int)(((u32)key) >> 16), x = (int)(((u32)key) & 0xFFFFu);
                 bool alive = valid;
                 int xc = 0, yc = 0;
