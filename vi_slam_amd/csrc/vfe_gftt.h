@@ -34,7 +34,9 @@ void gftt_eig_launch(const DImg& d, float* eigmap, u32* frame_max, u32* cand_cou
  * short pyramid launches in front of them) only start as its waves retire.  A long pass overlaps the whole tracker anyway;
  * a shorter one is better held to 3 or 2 workgroups per CU (requested as spare LDS per workgroup), and a short one is
  * better started behind the pyramid.  Measured on 1080p front-end steps, 8 to 256 streams (8640 strip rows per frame):
- * 256 streams uncapped, 128 three workgroups per CU (+3 %), 64 two (+7 %), 32 and fewer behind the pyramid (+4 .. +14 %).
+ * 256 streams uncapped, 128 three workgroups per CU (+3 %), 64 two (+7 %), 32 and fewer behind the pyramid (+4 .. +14 %);
+ * up to four streams the pass is the longest thing in the step and goes first again (1 / 2 / 4 streams: 0.114 / 0.124 /
+ * 0.144 ms per step behind the pyramid, 0.099 / 0.105 / 0.124 in front of it; 8 streams 0.185 against 0.193).
  * Where the pyramid is one launch of eight-wave workgroups (`pyramid_one_launch`), an uncapped pass in front of it leaves
  * no CU with room for such a workgroup until its own grid has been handed out: 256 streams 1.70 ms per step uncapped,
  * 1.61 ms with three workgroups per CU (behind the pyramid: 1.66). */
@@ -46,7 +48,8 @@ static inline EigBeside eig_beside_policy(int w, int h, int batch, bool pyramid_
     if (rows >= 1600000) return {pyramid_one_launch ? 3 : 0, false};
     if (rows >= 800000) return {3, false};
     if (rows >= 400000) return {2, false};
-    return {0, true};
+    if (rows >= 43200) return {0, true};
+    return {0, false};
 }
 
 /* the two halves of vfe_dev_good_features: the first depends on the image only and may be enqueued on another
