@@ -257,6 +257,25 @@ def test_good_features_with_many_seeds(cuda):
         assert np.array_equal(c[0, :k].cpu().numpy(), rxy)
 
 
+def test_good_features_busy_frame_with_tracked_points(cuda):
+    """Noise at 1080p with a low quality level on top of 900 tracked points: far more candidates above the threshold
+    than a workgroup of the selection holds in registers, so the rest is tested against the tracked points, and
+    cleared where blocked, in memory; several batches."""
+    import torch
+    w, h, n, d = 1920, 1080, 3000, 20
+    im = synth.noise(43, w, h)
+    seeds, _ = ora.good_features(synth.noise(44, w, h), 900, 0.001, d)
+    rxy, _ = ora.good_features(im, n - len(seeds), 0.0005, d, seeds=seeds)
+    gf = capi.GoodFeatures(1, h, w, n, seed_cap=n, device=cuda)
+    sd = torch.zeros((1, n, 2), dtype=torch.float32, device=cuda)
+    sd[0, :len(seeds)] = torch.from_numpy(seeds).to(cuda)
+    ns = torch.tensor([len(seeds)], dtype=torch.int32, device=cuda)
+    c, _, cnt = gf(to_dev([im], cuda), 0.0005, d, sd, ns)
+    k = int(cnt[0])
+    assert k == len(rxy) and k > 1000, f"{k} vs {len(rxy)}"
+    assert np.array_equal(c[0, :k].cpu().numpy(), rxy)
+
+
 def test_good_features_with_seeds(cuda):
     import torch
     w, h, n, d = 752, 480, 150, 30
