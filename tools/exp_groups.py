@@ -1,53 +1,46 @@
 #!/usr/bin/env python3
-"""Experiment: the 256 streams of the headline step as G independent groups, each on a HIP stream of its own, so that the
-tail of one group's kernel is filled by the other groups' work.  Usage: python3 tools/exp_groups.py [--batch 256] [--steps 100]"""
-import argparse, os, sys, time
+"""Experiment: the streams of a GPU stepped as G independent groups, each on a HIP stream of its own, against one batch
+(a group's chain of dependent launches leaves tails that another group's kernels can fill).
+Usage: python tools/exp_groups.py [streams] [groups ...]"""
+import os
+import sys
+import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 import bench
+from vi_slam_amd import capi
 
+dev = torch.device("cuda:0")
+total = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+groups = [int(a) for a in sys.argv[2:]] or [1, 2, 4]
+host = bench.make_frames(0, total, min(16, total), 4)
+frames = []
+for t in range(4):
+    d = capi.alloc_image(total, bench.H, bench.W, dev)
+    d.copy_(torch.from_numpy(host[t]).to(dev))
+    frames.append(d)
+for G in groups:
+    nb = total // G
+    streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
+    legs = []
+    for g in range(G):
+        with torch.cuda.stream(streams[g]):
+            legs.append(bench.FrontendLeg([f[g * nb:(g + 1) * nb] for f in frames], nb, 0.05, dev))
+    torch.cuda.synchronize()
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--groups", default="1,2,4")
-    args = ap.parse_args()
-    import torch
-    from vi_slam_amd import capi
-    dev = torch.device("cuda:0")
-    host = bench.make_frames(0, args.batch, 16, 4)
-    frames = []
-    for t in range(4):
-        d = capi.alloc_image(args.batch, bench.H, bench.W, dev)
-        d.copy_(torch.from_numpy(host[t]).to(dev))
-        frames.append(d)
-    for overlap in (True, False):
-        capi.set_overlap(overlap)
-        for G in [int(g) for g in args.groups.split(",")]:
-            per = args.batch // G
-            legs, streams = [], []
+    def run(steps):
+        for _ in range(steps):
             for g in range(G):
-                s = torch.cuda.Stream(device=dev)
-                with torch.cuda.stream(s):
-                    legs.append(bench.FrontendLeg([f[g * per:(g + 1) * per] for f in frames], per, 0.05, dev))
-                streams.append(s)
-            torch.cuda.synchronize()
-
-            def step():
-                for L, s in zip(legs, streams):
-                    with torch.cuda.stream(s):
-                        L.step()
-            for _ in range(5):
-                step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            print(f"overlap {int(overlap)} groups {G} x {per} streams: {dt / args.steps * 1e3:.3f} ms per step, {args.batch * args.steps / dt:,.0f} frames/s", flush=True)
-            del legs
-
-
-if __name__ == "__main__":
-    main()
+                with torch.cuda.stream(streams[g]):
+                    legs[g].step()
+    run(12)
+    torch.cuda.synchronize()
+    steps = 300
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pts = sum(float(L.fe.n_pts.float().mean()) for L in legs) / G
+    print(f"{total} streams as {G} group(s) of {nb}: {dt * 1e3:.4f} ms per step of all streams, {total / dt:.0f} frames/s "
+          f"(mean points {pts:.0f})", flush=True)
+    del legs
