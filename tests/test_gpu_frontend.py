@@ -789,3 +789,42 @@ def test_klt_track_with_workspace_gives_the_same_results(cuda, w, h, levels, npt
     # too small a workspace is an error, not a silent fallback
     with pytest.raises(capi.VfeError):
         capi.klt_track_ws(pl, nl, dP, dn, b_out, b_st, b_err, win=21, workspace=torch.empty(256, dtype=torch.uint8, device=cuda))
+
+
+@pytest.mark.parametrize("w,h,levels,batch,n,d", [(752, 480, 4, 3, 150, 30), (640, 360, 3, 2, 300, 12)])
+def test_frontend_stage_by_stage_equals_the_one_call(cuda, w, h, levels, batch, n, d):
+    """vfe_dev_build_pyramid + vfe_dev_frontend_candidates of the coming frame on a side stream beside
+    vfe_dev_frontend_track + vfe_dev_frontend_refill of the current one (capi.FrontendPipeline: two workspaces, three
+    pyramids) against vfe_dev_frontend_step, frame by frame over a sequence: the same points and counts, bit for bit."""
+    import torch
+    T = 7
+    seq = [[synth.scene(synth.BASE_SEED + 80 + b, w, h, t) for b in range(batch)] for t in range(T)]
+    dev_frames = [to_dev(f, cuda) for f in seq]
+    one = capi.FrontendStep(batch, h, w, n, levels, 21, quality=0.01, min_distance=float(d), device=cuda)
+    two = capi.FrontendPipeline(batch, h, w, n, levels, 21, quality=0.01, min_distance=float(d), device=cuda)
+    gf = capi.GoodFeatures(batch, h, w, n, device=cuda)
+    c, _, cnt = gf(dev_frames[0], 0.01, float(d))
+    for fe in (one, two):
+        fe.pts.copy_(c)
+        fe.n_pts.copy_(cnt)
+    pyr1 = [capi.alloc_pyramid(dev_frames[0], levels) for _ in range(2)]
+    pyr2 = [capi.alloc_pyramid(dev_frames[0], levels) for _ in range(3)]
+    for P in (pyr1, pyr2):
+        P[0][0] = dev_frames[0]
+        capi.build_pyramid(P[0])
+    for t in range(1, T):
+        a, b = pyr1[(t - 1) % 2], pyr1[t % 2]
+        b[0] = dev_frames[t]
+        one.step(a, b)
+        p, q, r = pyr2[(t - 1) % 3], pyr2[t % 3], pyr2[(t + 1) % 3]
+        q[0] = dev_frames[t]
+        coming = None
+        if t + 1 < T:
+            r[0] = dev_frames[t + 1]
+            coming = r
+        two.advance(p, q, coming)
+        torch.cuda.synchronize()
+        assert torch.equal(one.n_pts, two.n_pts), f"frame {t}"
+        assert torch.equal(one.n_tracked, two.n_tracked), f"frame {t}"
+        assert torch.equal(one.pts.view(torch.int32), two.pts.view(torch.int32)), f"frame {t}"
+    assert int(one.n_tracked.min()) > n // 3

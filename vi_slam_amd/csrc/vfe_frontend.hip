@@ -271,6 +271,70 @@ extern "C" int vfe_dev_frontend_step_fast(const vfe_dimg* prev_levels, const vfe
     return vfe_dev_append_points(pts, n_pts, cap, batch, corners, counts, L.ccap, stream);
 }
 
+/* The step stage by stage, for pipelines that hold the next frame before the current step has ended: the pyramid
+ * (vfe_dev_build_pyramid) and the detector's first pass touch the new frame only, the tracker needs both pyramids and the
+ * points, the refill needs the tracker's and the detector's results.  Same kernels, same arguments, same results as the one
+ * call; every stage runs on the stream it is given and the caller orders them. */
+static int fe_stage_args(const vfe_dimg* next_levels, int max_corners, void* workspace, size_t workspace_bytes, FeWs* L) {
+    VFE_REQUIRE(next_levels && workspace && max_corners > 0, "NULL buffer");
+    VFE_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+    int rc = vfe_check_dimg(&next_levels[0], "next level 0");
+    if (rc) return rc;
+    *L = fe_layout(next_levels[0].width, next_levels[0].height, next_levels[0].batch, max_corners);
+    if (workspace_bytes < L->total) {
+        vfe_set_error("workspace too small: need %zu bytes, got %zu", L->total, workspace_bytes);
+        return VFE_E_NOMEM;
+    }
+    return VFE_OK;
+}
+
+extern "C" int vfe_dev_frontend_candidates(const vfe_dimg* next_levels, int nlevels, int max_corners, double quality,
+                                           double min_distance, void* workspace, size_t workspace_bytes, void* stream) {
+    VFE_REQUIRE(nlevels >= 1 && nlevels <= 8, "nlevels must be 1..8");
+    FeWs L;
+    int rc = fe_stage_args(next_levels, max_corners, workspace, workspace_bytes, &L);
+    if (rc) return rc;
+    const int w = next_levels[0].width, h = next_levels[0].height, batch = next_levels[0].batch;
+    /* this pass runs beside the tracker of the frame before: the same sharing rule as inside the one call */
+    const EigBeside beside = eig_beside_policy(w, h, batch, vfe_pyramid_three_levels_per_launch(next_levels, nlevels));
+    return gf_eig_phase(&next_levels[0], max_corners, quality, min_distance, max_corners, (char*)workspace + L.gf_off, L.gf_bytes,
+                        (hipStream_t)stream, beside.wgs_per_cu);
+}
+
+extern "C" int vfe_dev_frontend_track(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
+                                      const float* pts, const int* n_pts, int max_corners,
+                                      int win, int max_iter, double eps, double min_eig_thr,
+                                      void* workspace, size_t workspace_bytes, const vfe_reject_opts* reject, void* stream) {
+    VFE_REQUIRE(prev_levels && nlevels >= 1 && nlevels <= 8, "nlevels must be 1..8");
+    VFE_REQUIRE(pts && n_pts, "NULL buffer");
+    FeWs L;
+    int rc = fe_stage_args(next_levels, max_corners, workspace, workspace_bytes, &L);
+    if (rc) return rc;
+    const int w = next_levels[0].width, h = next_levels[0].height, batch = next_levels[0].batch, cap = max_corners;
+    char* ws = (char*)workspace;
+    float* next_pts = (float*)(ws + L.next_off);
+    uint8_t* status = (uint8_t*)(ws + L.status_off);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* order = (cap <= 65536 && (long long)batch * cap >= 16384) ? (unsigned short*)(ws + L.order_off) : nullptr;
+    if (order && (rc = klt_order_launch(pts, n_pts, cap, batch, w, h, nlevels, order, st))) return rc;
+    if ((rc = klt_track_ordered(prev_levels, next_levels, nlevels, pts, n_pts, cap, next_pts, status, nullptr,
+                                win, max_iter, eps, min_eig_thr, 0, order, st))) return rc;
+    if (reject && reject->f_threshold > 0 && (rc = fe_reject(reject, pts, next_pts, n_pts, cap, batch, w, h, status, st))) return rc;
+    return VFE_OK;
+}
+
+extern "C" int vfe_dev_frontend_refill(const vfe_dimg* next_levels, float* pts, int* n_pts, int* n_tracked, int max_corners,
+                                       double quality, double min_distance, void* workspace, size_t workspace_bytes, void* stream) {
+    VFE_REQUIRE(pts && n_pts, "NULL buffer");
+    FeWs L;
+    int rc = fe_stage_args(next_levels, max_corners, workspace, workspace_bytes, &L);
+    if (rc) return rc;
+    char* ws = (char*)workspace;
+    return gf_select_phase(&next_levels[0], max_corners, quality, min_distance, pts, n_pts, max_corners, (float*)(ws + L.corners_off),
+                           nullptr, (int*)(ws + L.counts_off), ws + L.gf_off, L.gf_bytes, (hipStream_t)stream, true,
+                           (const float*)(ws + L.next_off), (const uint8_t*)(ws + L.status_off), n_tracked);
+}
+
 extern "C" int vfe_dev_frontend_step(const vfe_dimg* prev_levels, const vfe_dimg* next_levels, int nlevels,
                                      float* pts, int* n_pts, int* n_tracked, int max_corners,
                                      double quality, double min_distance,
