@@ -9,9 +9,11 @@
  *                the final quality threshold are dropped early against the running maximum
  *                (a lower bound of the final one), which only removes keys the exact filter
  *                would remove anyway.
- *  k_gftt_select one workgroup per frame: exact threshold, then candidates are consumed in
- *                descending key order in batches (radix select of the next <= 8192 keys, bitonic
- *                sort in LDS) by a wave-parallel version of OpenCV's greedy min-distance walk:
+ *  k_gftt_select one workgroup per frame: exact threshold (the keys that pass are packed into the
+ *                threads' registers), candidates next to a tracked point dropped, then the rest is consumed in
+ *                descending key order in batches (radix select of the next 512 .. 8192 keys, bitonic
+ *                sort -- in registers up to 1024 keys, vfe_sort.h, in LDS beyond) by a wave-parallel
+ *                version of OpenCV's greedy min-distance walk:
  *                64 candidates are tested against the accepted set at once, conflicts inside
  *                the 64 are resolved in rank order with ballots.  The result equals the serial
  *                walk because a candidate's fate depends only on higher-ranked ones.
