@@ -345,10 +345,15 @@ class FrontendLeg:
         self.keep_num = int(round((1.0 - min(max(loss, 0.0), 1.0)) * self.keep_den))
 
     def drop_tracks(self):
-        """n <- floor(n * keep): the newest tracks of every stream are dropped (two element-wise torch kernels)."""
+        """n <- floor(n * keep): the newest tracks of every stream are dropped.  One torch kernel: a look-up in the table of
+        floor(n * keep) for n = 0 .. NFEAT into a spare count array, which then changes places with the step's."""
         torch = self.torch
-        torch.mul(self.fe.n_pts, self.keep_num, out=self.fe.n_pts)
-        torch.div(self.fe.n_pts, self.keep_den, rounding_mode="floor", out=self.fe.n_pts)
+        fe = self.fe
+        if getattr(fe, "keep_table", None) is None:
+            fe.keep_table = (torch.arange(NFEAT + 1, dtype=torch.int64, device=fe.n_pts.device) * self.keep_num // self.keep_den).to(torch.int32)
+            fe.n_spare = torch.zeros_like(fe.n_pts)
+        torch.index_select(fe.keep_table, 0, fe.n_pts, out=fe.n_spare)
+        fe.n_pts, fe.n_spare = fe.n_spare, fe.n_pts
 
     def step(self):
         nxt = self.cur ^ 1
@@ -487,9 +492,9 @@ def run_frontend_leg(rk, frames, batch, loss, steps, warmup, counters, leg, over
                 f"({k_elapsed / k_steps * 1e3:.3f} ms per step); in the timed region the eigenvalue pass runs beside pyramid + tracker")
     kernels = kernel_table(prof, k_elapsed, {k: v * batch for k, v in ALGO_BYTES.items()}, k_steps)
     extra_ms = L.torch_kernels_ms() if L.keep_num < L.keep_den else 0.0
-    kernels["torch_track_loss"] = {"launches": 2 * k_steps, "avg_ms": extra_ms / 2, "share": extra_ms * k_steps / (k_elapsed * 1e3),
+    kernels["torch_track_loss"] = {"launches": k_steps, "avg_ms": extra_ms, "share": extra_ms * k_steps / (k_elapsed * 1e3),
                                    "algo_bytes_per_launch": 8 * batch, "algo_GBs": None,
-                                   "what": "n_pts <- floor(n_pts * keep): two element-wise torch kernels per step, timed apart"}
+                                   "what": "n_pts <- floor(n_pts * keep): one torch look-up kernel per step, timed apart"}
     tracked = float(L.fe.n_tracked.float().mean().item())
     points = float(L.fe.n_pts.float().mean().item())
     tracks = {"mean_tracked": tracked, "mean_points": points}
