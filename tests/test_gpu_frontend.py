@@ -791,8 +791,9 @@ def test_klt_track_with_workspace_gives_the_same_results(cuda, w, h, levels, npt
         capi.klt_track_ws(pl, nl, dP, dn, b_out, b_st, b_err, win=21, workspace=torch.empty(256, dtype=torch.uint8, device=cuda))
 
 
-@pytest.mark.parametrize("w,h,levels,batch,n,d", [(752, 480, 4, 3, 150, 30), (640, 360, 3, 2, 300, 12)])
-def test_frontend_stage_by_stage_equals_the_one_call(cuda, w, h, levels, batch, n, d):
+@pytest.mark.parametrize("w,h,levels,batch,n,d,f_thr", [(752, 480, 4, 3, 150, 30, 0.0), (640, 360, 3, 2, 300, 12, 0.0),
+                                                        (752, 480, 4, 2, 150, 30, 1.0)])
+def test_frontend_stage_by_stage_equals_the_one_call(cuda, w, h, levels, batch, n, d, f_thr):
     """vfe_dev_build_pyramid + vfe_dev_frontend_candidates of the coming frame on a side stream beside
     vfe_dev_frontend_track + vfe_dev_frontend_refill of the current one (capi.FrontendPipeline: two workspaces, three
     pyramids) against vfe_dev_frontend_step, frame by frame over a sequence: the same points and counts, bit for bit."""
@@ -807,6 +808,8 @@ def test_frontend_stage_by_stage_equals_the_one_call(cuda, w, h, levels, batch, 
     for fe in (one, two):
         fe.pts.copy_(c)
         fe.n_pts.copy_(cnt)
+        if f_thr > 0:  # the epipolar filter between tracker and refill, in both forms
+            fe.set_f_rejection(f_thr, camera=(458.654, 457.296, w / 2.0, h / 2.0), dist=(-0.28, 0.07, 0.0002, 0.00002, 0.0))
     pyr1 = [capi.alloc_pyramid(dev_frames[0], levels) for _ in range(2)]
     pyr2 = [capi.alloc_pyramid(dev_frames[0], levels) for _ in range(3)]
     for P in (pyr1, pyr2):

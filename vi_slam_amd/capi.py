@@ -469,8 +469,9 @@ class FrontendPipeline(FrontendStep):
         # end of the step (64 streams: 0.68 against 0.55 ms per step).
         cur.wait_event(self.pyramid_done[self.slot])
         cur.wait_event(self.candidates_done[self.slot])
+        rj = C.byref(self.reject) if getattr(self, "reject", None) is not None else None
         check(lib().vfe_dev_frontend_track(pa, na, n, _ptr(self.pts), _ptr(self.n_pts), self.cap, self.win, self.max_iter, self.eps,
-                                           self.min_eig_thr, _ptr(ws), self.ws_bytes, None, _stream()))
+                                           self.min_eig_thr, _ptr(ws), self.ws_bytes, rj, _stream()))
         check(lib().vfe_dev_frontend_refill(na, _ptr(self.pts), _ptr(self.n_pts), _ptr(self.n_tracked), self.cap, self.quality,
                                             self.min_distance, _ptr(ws), self.ws_bytes, _stream()))
         self.consumed[self.slot].record()
