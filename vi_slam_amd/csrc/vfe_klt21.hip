@@ -262,6 +262,15 @@ __device__ static inline void piece_pass(const unsigned* area, int row, int dw, 
     piece_mismatch<NPX>(v, Tx, Ty, b1, b2);
     __builtin_amdgcn_sched_barrier(0);
 }
+/* the same with the piece's rows already in registers (read while the piece before it was being computed) */
+template <int NPX>
+__device__ static inline void piece_pass_rows(const unsigned (&w)[2][3], unsigned W0, unsigned W1,
+                                              const unsigned* Tx, const unsigned* Ty, int& b1, int& b2) {
+    int v[NPX];
+    piece_values<NPX>(w, W0, W1, v);
+    piece_mismatch<NPX>(v, Tx, Ty, b1, b2);
+    __builtin_amdgcn_sched_barrier(0);
+}
 /* sum |J - I| over the first nvalid pixels of a piece; both patches staged (22-row layout) */
 template <int NPX>
 __device__ static inline int piece_residual(const unsigned* areaJ, const unsigned* areaI, int row, int dw, int nvalid,
@@ -432,10 +441,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
                     break;
                 }
                 int b1 = 0, b2 = 0, e1 = 0, e2 = 0;
-                piece_pass<8>(area, sub, 0, W0, W1, TxA, TyA, b1, b2);
-                piece_pass<8>(area, sub, 2, W0, W1, TxA + 4, TyA + 4, b1, b2);
-                piece_pass<5>(area, sub, 4, W0, W1, TxA + 8, TyA + 8, b1, b2);
-                piece_pass<8>(area, L.rB, L.cB / 4, W0, W1, TxB, TyB, e1, e2);
+                {
+                    /* a piece's rows are read from LDS while the piece before it is computed */
+                    unsigned wa[2][3], wb[2][3];
+                    read_piece<2>(area, sub, 0, wa);
+                    read_piece<2>(area, sub, 2, wb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece_pass_rows<8>(wa, W0, W1, TxA, TyA, b1, b2);
+                    read_piece<2>(area, sub, 4, wa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece_pass_rows<8>(wb, W0, W1, TxA + 4, TyA + 4, b1, b2);
+                    read_piece<2>(area, L.rB, L.cB / 4, wb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece_pass_rows<5>(wa, W0, W1, TxA + 8, TyA + 8, b1, b2);
+                    piece_pass_rows<8>(wb, W0, W1, TxB, TyB, e1, e2);
+                }
                 if (L.hasB) { b1 += e1; b2 += e2; }
                 const float fb1 = row_sum_to_float(b1 - c1) * FLT_SCALE, fb2 = row_sum_to_float(b2 - c2) * FLT_SCALE;
                 const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
