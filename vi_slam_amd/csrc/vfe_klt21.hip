@@ -384,21 +384,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT21_WPE, K
                 /* gradients are needed at columns ipx .. ipx+21, rows ipy .. ipy+21 */
                 const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < I.w && ipy + win < I.h;
                 int b11 = 0, b12 = 0, b22 = 0, d1 = 0, d2 = 0;
-                unsigned w[4][3];
+                unsigned w[4][3], w2[4][3]; /* a piece's rows are read while the piece before it is computed */
                 PieceCarry carry;
                 /* wave-uniform choice: the masked variant only when some point of the wave needs it */
 #define KLT_TEMPLATE_PIECES(MASKED)                                                                                        \
     read_piece<4>(area, sub, 0, w);                                                                                        \
+    read_piece<4>(area, sub, 2, w2);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
     piece_template<8, MASKED, false, true>(w, Wt0, Wt1, interior, ipx, ipy + sub, I.w, I.h, 8, TxA, TyA, a11, a12, a22, c1, c2, carry); \
     __builtin_amdgcn_sched_barrier(0);                                                                                     \
-    read_piece<4>(area, sub, 2, w);                                                                                        \
-    piece_template<8, MASKED, true, true>(w, Wt0, Wt1, interior, ipx + 8, ipy + sub, I.w, I.h, 8, TxA + 4, TyA + 4, a11, a12, a22, c1, c2, carry); \
-    __builtin_amdgcn_sched_barrier(0);                                                                                     \
     read_piece<4>(area, sub, 4, w);                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    piece_template<8, MASKED, true, true>(w2, Wt0, Wt1, interior, ipx + 8, ipy + sub, I.w, I.h, 8, TxA + 4, TyA + 4, a11, a12, a22, c1, c2, carry); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    read_piece<4>(area, L.rB, L.cB / 4, w2);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
     piece_template<5, MASKED, true, false>(w, Wt0, Wt1, interior, ipx + 16, ipy + sub, I.w, I.h, 5, TxA + 8, TyA + 8, a11, a12, a22, c1, c2, carry); \
     __builtin_amdgcn_sched_barrier(0);                                                                                     \
-    read_piece<4>(area, L.rB, L.cB / 4, w);                                                                                \
-    piece_template<8, MASKED, false, false>(w, Wt0, Wt1, interior, ipx + L.cB, ipy + L.rB, I.w, I.h, L.nB, TxB, TyB, b11, b12, b22, d1, d2, carry); \
+    piece_template<8, MASKED, false, false>(w2, Wt0, Wt1, interior, ipx + L.cB, ipy + L.rB, I.w, I.h, L.nB, TxB, TyB, b11, b12, b22, d1, d2, carry); \
     __builtin_amdgcn_sched_barrier(0);
                 if (__builtin_amdgcn_ballot_w64(!interior) != 0) { KLT_TEMPLATE_PIECES(true) } else { KLT_TEMPLATE_PIECES(false) }
 #undef KLT_TEMPLATE_PIECES
